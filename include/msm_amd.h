@@ -1,0 +1,269 @@
+/* msm_amd — MI355X (gfx950) multilevel-summation engine, C ABI.
+ *
+ * Two layers are exported by libmsm_amd.so:
+ *
+ *  (1) the drop-in layer: the symbols a driver written against the reference's
+ *      msm/msmLibrary.h links to (msmperiodic, msmPeriodicRunner, chooseM, ...,
+ *      print_stats, data_read, the linked-list helpers), same signatures, same
+ *      msm_stats layout (960 bytes), computed on the GPU;
+ *  (2) the handle layer (msm_amd_*): an explicit plan + device-resident
+ *      evaluation for callers that keep particles in HBM, and per-stage entry
+ *      points used by the parity tests and by the multi-GPU slab driver.
+ *
+ * All pointers are plain host or device pointers as stated per function; no
+ * C++ or torch types cross this boundary.  Every function that can fail
+ * returns 0 on success and a negative MSM_AMD_E* code otherwise;
+ * msm_amd_last_error() gives the text.  There is no CPU fallback: without a
+ * usable HIP device every compute entry point fails with MSM_AMD_ENODEV.
+ */
+#ifndef MSM_AMD_H
+#define MSM_AMD_H
+
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+/* ------------------------------------------------------------------ */
+/* (1) drop-in layer                                                    */
+/* ------------------------------------------------------------------ */
+
+#define MAXDIM 3
+#define LMAX 10
+#define DIMX 0
+#define DIMY 1
+#define DIMZ 2
+#define MAX_POLY_DEGREE 6
+#define MAX_MU 14
+#ifndef PI
+#define PI 3.14159265358979323846
+#endif
+#define VERYLARGENUMBER 1e30
+
+/* replaces struct Parameters, msm/msmLibrary.h:22-30 (unused by the reference itself) */
+typedef struct Parameters {
+    double abar;
+    int mu;
+    int p;
+    double Ax, Ay, Az;
+} Parameters;
+
+/* replaces msm/msmLibrary.h:32-44 */
+typedef struct LinkedListElement {
+    int data;
+    double value;
+    struct LinkedListElement *next;
+    struct LinkedListElement *prev;
+} LinkedListElement;
+
+typedef struct LinkedList {
+    struct LinkedListElement *head;
+    struct LinkedListElement *tail;
+} LinkedList;
+
+/* Result record, binary compatible with msm/msmLibrary.h:46-110 (960 bytes;
+ * N at 0, h 16, beta 72, csr 96, cvecx 120, chi 168, Mx 204, Mlx 240,
+ * slsizex 360, Ax 480, rminx 616, volume 664, netcharge 696,
+ * cputime_initialization 784, potential_total 888, potential_long_fourier 952).
+ * cvecx/cvecy/cvecz/chi are malloc'ed host arrays the caller may read (and
+ * free); print_stats reads clenx.. / chisize entries of them. */
+typedef struct msm_stats {
+    int N, L, mu;
+    double h, hx, hy, hz, a, aL, alpha, beta;
+    int p, s, kmax;
+    double csr;
+    int chinx, chiny, chinz, chisize;
+    double *cvecx, *cvecy, *cvecz;
+    int clenx, cleny, clenz;
+    double chisum, *chi;
+    int sLsize, sLnx, sLny, sLnz;
+    int M0[MAXDIM];
+    int Mx, My, Mz;
+    int MLx, MLy, MLz;
+    int ML2x, ML2y, ML2z;
+    int Mlx[LMAX], Mly[LMAX], Mlz[LMAX];
+    int slsizex[LMAX], slsizey[LMAX], slsizez[LMAX];
+    int Ax, Ay, Az;
+    int size[LMAX][MAXDIM];
+    double rminx, rminy, rminz, rmaxx, rmaxy, rmaxz;
+    double volume, density;
+    long int short_range_interactions;
+    int storage;
+    double netcharge;
+    double netgridcharge[LMAX];
+    double cputime_initialization, cputime_anterpolation, cputime_restriction, cputime_stencill, cputime_stencilL,
+        cputime_grid_to_grid_mapping, cputime_top_level, cputime_prolongation, cputime_interpolation,
+        cputime_potential_long, cputime_short_range, cputime_self, cputime_total;
+    double potential_total, potential_short_total, potential_short_real, potential_short_csr, potential_short_self,
+        potential_long_total, potential_long_real, potential_long_self, potential_long_fourier;
+} msm_stats;
+
+/* Periodic MSM energy + per-particle accelerations on the GPU.
+ * replaces msmperiodic(), msm/msmLibrary.h:188-189, defined at msm/msmPeriodic.c:52.
+ * r[3N] (AoS), q[N] host in; *uappr and fappr[3N] host out (overwritten).
+ * In literal mode (see msm_amd_set_mode) the caller's r is shifted by +0.5 as
+ * the reference does (msmPeriodic.c:75-76). */
+msm_stats msmperiodic(int N, double *r, double *q, int p, double abar, int mu, double *uappr, double *fappr, double Ax,
+                      double Ay, double Az);
+/* replaces msmPeriodicRunner(), msm/msmLibrary.h:249, msm/msmPeriodic.c:1458 */
+double msmPeriodicRunner(double *r, double *q, double *f, int n, int p, int mu, double abar, double Lx, double Ly,
+                         double Lz);
+
+/* parameter helpers, msm/msmLibrary.h:191-192,238-247 / msm/msmLibrary.c:3,31,46,69,110,283 */
+double mylog2(double x);
+double choosebetaNew(double epsilon, double aL, double hL);
+double choosekmax(double epsilon, double beta, double hL);
+int chooseM(double htilde, double Ax);
+int chooseL(int Mx, int My, int Mz, int N);
+int minOf3Integers(int a, int b, int c);
+/* msm/msmLibrary.h:245 / msmLibrary.c:7; unlike the reference a missing file returns 1 instead of crashing */
+int data_read(char *filename, double **q, double **r, int *N, double *Lx, double *Ly, double *Lz);
+/* msm/msmLibrary.h:214 / msmLibrary.c:125 (host, one pair; the GPU pair kernels are its batched form) */
+double short_range_periodic(int i, int j, double *r, double *q, int s, double a, double *fshort, double Ax, double Ay,
+                            double Az);
+/* msm/msmLibrary.h:215 / msmLibrary.c:290 */
+void print_stats(msm_stats stats);
+/* msm/msmLibrary.h:199-204 / msmLibrary.c:183-281 */
+LinkedList *msm4g_linkedlist_new();
+void msm4g_linkedlist_add(LinkedList *list, int data);
+void msm4g_linkedlist_addvalue(LinkedList *list, int data, double value);
+int msm4g_linkedlist_search(LinkedList *list, int data);
+double msm4g_linkedlist_getvalue(LinkedList *list, int index);
+void msm4g_linkedlist_destroy(LinkedList *list);
+
+/* ------------------------------------------------------------------ */
+/* (2) handle layer (no counterpart in the reference; it is what       */
+/*     msmperiodic() is built from)                                    */
+/* ------------------------------------------------------------------ */
+
+enum {
+    MSM_AMD_OK = 0,
+    MSM_AMD_EINVAL = -1,  /* bad argument / unsupported parameter combination */
+    MSM_AMD_ENODEV = -2,  /* no usable HIP device */
+    MSM_AMD_EHIP = -3,    /* a HIP runtime call failed */
+    MSM_AMD_ENOMEM = -4,
+    MSM_AMD_ERANGE = -5   /* size beyond what the selected mode supports */
+};
+
+/* how msmperiodic() maps onto the engine */
+enum {
+    MSM_AMD_MODE_AUTO = 0,    /* literal when N <= 4096 (the only regime the reference algorithm can run), else scalable */
+    MSM_AMD_MODE_LITERAL = 1, /* reproduce msmPeriodic.c stage by stage, index conventions included */
+    MSM_AMD_MODE_SCALABLE = 2 /* consistent indexing, multilevel, O(N) */
+};
+void msm_amd_set_mode(int mode);
+int msm_amd_get_mode(void);
+/* quiet != 0 suppresses the stencil / grid-charge dumps msmperiodic() prints in literal mode (msmPeriodic.c:600-610,723-733) */
+void msm_amd_set_quiet(int quiet);
+
+/* what the acceleration output contains */
+enum {
+    MSM_AMD_ACC_GRADIENT = 0, /* acc_i = sum_j q_j g0'(r) rhat + sum_m e_m grad phi_m(r_i)  (msmSimple.c:846,1330,1370) */
+    MSM_AMD_ACC_LITERAL = 1,  /* fshort_i = sum_j (q_i+q_j)/2 g0' rhat (msmLibrary.c:168-176); flong_i = q_i * grid part (msmPeriodic.c:1158) */
+    MSM_AMD_ACC_FORCE = 2     /* electrostatic force  F_i = -q_i * gradient form */
+};
+
+typedef struct msm_amd_plan_desc {
+    int N;          /* particles this handle evaluates (owned + halo on a slab rank) */
+    int p;          /* B-spline order, 4 or 6 */
+    int mu;         /* quasi-interpolation width */
+    int L;          /* number of real-space grid levels (>= 1) */
+    int kmax;       /* Fourier cutoff of the top level */
+    int acc_convention;
+    int M[3];       /* level-0 grid */
+    int zplane0;    /* first level-0 z plane owned by this rank (0 for single GPU) */
+    int nzplanes;   /* number of owned level-0 z planes (M[2] for single GPU) */
+    int n_owned;    /* particles [0, n_owned) are owned, the rest are halo copies; 0 means all N */
+    double A[3];    /* periodic cell */
+    double a;       /* short-range cutoff */
+    double beta;    /* Ewald splitting of the top level */
+} msm_amd_plan_desc;
+
+/* The reference's parameter choices (msmPeriodic.c:147-263) for L levels:
+ * htilde=(V/N)^(1/3), M=chooseM per axis, a=abar*htilde, beta=choosebetaNew(1e-12,2^L a,2^(L-1)hx),
+ * kmax=ceil|choosekmax|.  L<=0 selects min(allowed, wanted) of msmLibrary.c:46-62 capped so that the
+ * coarsest grid has at least 8 nodes per axis. */
+int msm_amd_plan_auto(int N, double Ax, double Ay, double Az, int p, int mu, double abar, int L, msm_amd_plan_desc *out);
+
+typedef struct msm_amd_handle msm_amd_handle;
+
+/* Builds omega', all stencils (host, position independent) and allocates every device buffer.
+ * stream: a hipStream_t (NULL = the null stream) on which every later launch of this handle is queued. */
+int msm_amd_create(const msm_amd_plan_desc *plan, int device, void *stream, msm_amd_handle **out);
+/* Same, but every stage follows msmPeriodic.c's own index conventions (needs L=1, p=4, mu<=11); this is what
+ * msmperiodic() runs in literal mode. */
+int msm_amd_create_literal(const msm_amd_plan_desc *plan, int device, void *stream, msm_amd_handle **out);
+void msm_amd_destroy(msm_amd_handle *h);
+
+enum { MSM_AMD_U_SHORT_REAL = 0, MSM_AMD_U_SHORT_SELF, MSM_AMD_U_SHORT_CSR, MSM_AMD_U_LONG_REAL, MSM_AMD_U_LONG_FOUR,
+       MSM_AMD_U_LONG_SELF, MSM_AMD_U_TOTAL, MSM_AMD_U_COUNT };
+
+/* One energy + acceleration evaluation, everything device resident.
+ * d_r[3N] AoS, d_q[N], d_acc[3N] device pointers; energies[MSM_AMD_U_COUNT] host out (may be NULL: then
+ * nothing is copied back and the call does not synchronise). */
+int msm_amd_eval(msm_amd_handle *h, const double *d_r, const double *d_q, double *d_acc, double *energies);
+/* Same through host buffers (H2D 32 B/particle + D2H 24 B/particle included). */
+int msm_amd_eval_host(msm_amd_handle *h, const double *r, const double *q, double *acc, double *energies);
+
+/* ---- stage entry points (device pointers unless noted) ---- */
+/* bin particles; must precede pairs/anterpolate/interpolate of the same positions */
+int msm_amd_stage_bin(msm_amd_handle *h, const double *d_r, const double *d_q);
+/* d_acc[3N] <- short-range part (per acc_convention); partial energy kept in the handle */
+int msm_amd_stage_pairs(msm_amd_handle *h, double *d_acc);
+/* level-0 grid charges of planes [zplane0, zplane0+nzplanes) */
+int msm_amd_stage_anterpolate(msm_amd_handle *h);
+/* restriction -> per-level convolutions -> top level -> prolongation on the whole grids held by the handle */
+int msm_amd_stage_grid(msm_amd_handle *h);
+/* d_acc[3N] += grid part */
+int msm_amd_stage_interpolate(msm_amd_handle *h, double *d_acc);
+/* reductions; energies[MSM_AMD_U_COUNT] host out */
+int msm_amd_stage_energies(msm_amd_handle *h, double *energies);
+
+/* device pointers / copies of internal state (for the slab all-gather and the tests) */
+enum { MSM_AMD_GRID_Q = 0, MSM_AMD_GRID_E = 1, MSM_AMD_GRID_EFOUR = 2 };
+void *msm_amd_grid_device_ptr(msm_amd_handle *h, int which, int level);
+int msm_amd_grid_dims(msm_amd_handle *h, int level, int dims[3]);
+int msm_amd_copy_grid(msm_amd_handle *h, int which, int level, double *host_out);
+int msm_amd_set_grid(msm_amd_handle *h, int which, int level, const double *host_in);
+/* stencil of level l (host copy, x fastest); level == L selects the Fourier top stencil */
+int msm_amd_stencil_info(msm_amd_handle *h, int level, int size[3], int first[3]);
+int msm_amd_copy_stencil(msm_amd_handle *h, int level, double *host_out);
+int msm_amd_copy_wprime(msm_amd_handle *h, double *host_out, int *len);
+/* single grid operators on caller-supplied device arrays (parity tests of one operator) */
+int msm_amd_op_restrict(msm_amd_handle *h, int level, const double *d_fine, double *d_coarse);
+int msm_amd_op_prolong_add(msm_amd_handle *h, int level, const double *d_coarse, double *d_fine);
+int msm_amd_op_convolve(msm_amd_handle *h, int level, const double *d_q, double *d_e);
+/* per-kernel wall time of the last msm_amd_eval in milliseconds (HIP events on the handle's stream):
+ * [bin, pairs, anterpolation, restriction, convolution, top, prolongation, interpolation, reductions, total] */
+int msm_amd_last_timings(msm_amd_handle *h, double ms[10]);
+/* enable per-stage event timing (adds event records to the stream); off by default */
+void msm_amd_set_profiling(msm_amd_handle *h, int on);
+/* select kernel variants (for A/B benchmarking); key/value, returns MSM_AMD_EINVAL for unknown keys */
+int msm_amd_set_option(msm_amd_handle *h, const char *key, int value);
+
+/* Host-only view of a plan (no device needed): omega', J, stencils.  Used to validate the position-independent
+ * setup on machines without a GPU and to export stencils. */
+typedef struct msm_amd_hostplan msm_amd_hostplan;
+int msm_amd_hostplan_create(const msm_amd_plan_desc *plan, int literal, msm_amd_hostplan **out);
+void msm_amd_hostplan_destroy(msm_amd_hostplan *hp);
+int msm_amd_hostplan_stencil_info(msm_amd_hostplan *hp, int level, int size[3], int first[3]);
+int msm_amd_hostplan_copy_stencil(msm_amd_hostplan *hp, int level, double *host_out);
+int msm_amd_hostplan_copy_wprime(msm_amd_hostplan *hp, double *host_out, int *len);
+/* scalars: [csr, self_image_sum, gamma(0), chisum, J0, J1, J2, J3] */
+int msm_amd_hostplan_scalars(msm_amd_hostplan *hp, double out[8]);
+
+const char *msm_amd_last_error(void);
+int msm_amd_device_count(void);
+const char *msm_amd_version(void);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSM_AMD_H */

@@ -1,0 +1,10 @@
+"""msm_amd — MI355X-native multilevel summation (MSM) electrostatics.
+
+The compute path is libmsm_amd.so (hand-written gfx950 kernels behind a C ABI,
+see include/msm_amd.h).  This package only binds it.
+"""
+from . import capi
+from .capi import MsmAmdError, load
+from .engine import Engine, HostPlan, msmperiodic, plan_auto, plan_explicit
+
+__all__ = ["capi", "MsmAmdError", "load", "Engine", "HostPlan", "msmperiodic", "plan_auto", "plan_explicit"]

@@ -1,0 +1,712 @@
+// Handle layer + the drop-in msmperiodic()/msmPeriodicRunner() built on it.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "msm_amd.h"
+#include "msm_host.hpp"
+#include "msm_kernels.hpp"
+
+using namespace msm;
+
+#define HIPCHK(call)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);     \
+            return MSM_AMD_EHIP;                                                                      \
+        }                                                                                             \
+    } while (0)
+
+enum { T_BIN = 0, T_PAIR, T_ANT, T_RES, T_CONV, T_TOP, T_PRO, T_INT, T_RED, T_TOTAL, T_COUNT };
+static const int NPARTS = 256;
+
+struct msm_amd_handle {
+    HostPlan hp;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int N = 0, n_owned = 0;
+    bool small_box = false;
+    int nc[3] = {0, 0, 0}, ncell = 0;
+    BinGeom cellg, gridg;
+    PairParams pp;
+    SplineParams sp;
+    // particles
+    double4 *ps_cell = nullptr, *ps_grid = nullptr;
+    int *order_cell = nullptr, *order_grid = nullptr, *bin_of = nullptr, *slot_idx = nullptr;
+    int *ccount = nullptr, *cstart = nullptr, *cfill = nullptr, *gcount = nullptr, *gstart = nullptr, *gfill = nullptr;
+    int *scan_tmp = nullptr;
+    // grids
+    std::vector<double *> gq, ge, dK, dKt;
+    double *efour = nullptr, *dKL = nullptr, *tmpA = nullptr, *tmpB = nullptr;
+    // reductions
+    double *epart = nullptr;
+    int nepart = 0;
+    double *parts = nullptr; // [grid NPARTS | four NPARTS | charge 2*NPARTS]
+    double *d_energies = nullptr, *h_energies = nullptr;
+    const double *cur_r = nullptr, *cur_q = nullptr;
+    // host staging for eval_host
+    double *s_r = nullptr, *s_q = nullptr, *s_acc = nullptr;
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev[T_COUNT + 1];
+    bool ev_made = false;
+    double last_ms[T_COUNT];
+    int opt_pair_variant = 1, opt_conv_tiled = 1;
+};
+
+static int g_mode = MSM_AMD_MODE_AUTO;
+static int g_quiet = 0;
+
+extern "C" void msm_amd_set_mode(int mode) { g_mode = mode; }
+extern "C" int msm_amd_get_mode(void) { return g_mode; }
+extern "C" void msm_amd_set_quiet(int quiet) { g_quiet = quiet; }
+
+extern "C" int msm_amd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+template <typename T>
+static int dalloc(T **p, size_t n) {
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e != hipSuccess) {
+        set_error("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+        return MSM_AMD_ENOMEM;
+    }
+    return MSM_AMD_OK;
+}
+
+static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, void *stream, msm_amd_handle **out) {
+    if (!plan || !out) { set_error("msm_amd_create: null argument"); return MSM_AMD_EINVAL; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        set_error("no HIP device is visible; msm_amd has no CPU path");
+        return MSM_AMD_ENODEV;
+    }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d visible)", device, ndev); return MSM_AMD_EINVAL; }
+    HIPCHK(hipSetDevice(device));
+    msm_amd_handle *h = new msm_amd_handle();
+    h->hp.d = *plan;
+    h->hp.literal = literal;
+    if (h->hp.d.nzplanes <= 0) { h->hp.d.zplane0 = 0; h->hp.d.nzplanes = plan->M[2]; }
+    if (h->hp.d.zplane0 < 0 || h->hp.d.zplane0 + h->hp.d.nzplanes > plan->M[2]) {
+        set_error("owned z planes [%d,%d) outside the grid", h->hp.d.zplane0, h->hp.d.zplane0 + h->hp.d.nzplanes);
+        delete h;
+        return MSM_AMD_EINVAL;
+    }
+    int rc = build_host_plan(h->hp);
+    if (rc) { delete h; return rc; }
+    const msm_amd_plan_desc &d = h->hp.d;
+    h->device = device;
+    h->stream = (hipStream_t)stream;
+    h->N = d.N;
+    h->n_owned = (d.n_owned > 0 && d.n_owned <= d.N) ? d.n_owned : d.N;
+    const int N = d.N, L = d.L;
+
+    // pair cells: edge >= a; with fewer than 3 cells on an axis a pair can see several images -> all-images kernel
+    for (int k = 0; k < 3; k++) h->nc[k] = (int)std::floor(d.A[k] / d.a);
+    h->small_box = h->nc[0] < 3 || h->nc[1] < 3 || h->nc[2] < 3;
+    if (h->small_box && N > 65536) {
+        set_error("cutoff a=%g exceeds a third of the cell: the all-images pair kernel is limited to N<=65536", d.a);
+        delete h;
+        return MSM_AMD_ERANGE;
+    }
+    if (h->small_box && (d.nzplanes != d.M[2] || h->n_owned != N)) {
+        set_error("slab decomposition needs at least 3 pair cells per axis");
+        delete h;
+        return MSM_AMD_EINVAL;
+    }
+    h->ncell = h->small_box ? 1 : h->nc[0] * h->nc[1] * h->nc[2];
+    for (int k = 0; k < 3; k++) {
+        h->cellg.nb[k] = h->small_box ? 1 : h->nc[k];
+        h->cellg.invA[k] = 1.0 / d.A[k];
+        h->cellg.scale[k] = d.A[k];
+        h->gridg.nb[k] = d.M[k];
+        h->gridg.invA[k] = 1.0 / d.A[k];
+        h->gridg.scale[k] = (double)d.M[k];
+    }
+    h->cellg.nbins = h->ncell;
+    h->gridg.nbins = d.M[0] * d.M[1] * d.M[2];
+
+    PairParams &pp = h->pp;
+    for (int k = 0; k < 3; k++) { pp.nc[k] = h->nc[k]; pp.A[k] = d.A[k]; }
+    pp.a2 = d.a * d.a;
+    pp.inv_a = 1.0 / d.a;
+    pp.inv_a2 = 1.0 / (d.a * d.a);
+    pp.inv_a3 = 1.0 / (d.a * d.a * d.a);
+    gamma_poly(d.p, pp.cg, pp.cd);
+    pp.p = d.p;
+    pp.convention = d.acc_convention;
+
+    SplineParams &sp = h->sp;
+    sp.p = d.p;
+    for (int k = 0; k < 3; k++) {
+        sp.M[k] = d.M[k];
+        sp.inv_h[k] = 1.0 / h->hp.hl[0][k];
+        // literal anterpolation: array index j holds node j - (M/2 - 1), and an odd M leaves its last plane
+        // empty (msmPeriodic.c:697-702)
+        sp.node_shift[k] = literal ? d.M[k] / 2 - 1 : 0;
+        sp.drop_last[k] = (literal && (d.M[k] & 1)) ? 1 : 0;
+    }
+    sp.z0 = d.zplane0;
+    sp.nz = d.nzplanes;
+    sp.convention = d.acc_convention;
+
+#define DA(ptr, n)                      \
+    do {                                \
+        rc = dalloc(&(ptr), (size_t)(n)); \
+        if (rc) { msm_amd_destroy(h); return rc; } \
+    } while (0)
+    DA(h->ps_cell, N); DA(h->ps_grid, N); DA(h->order_cell, N); DA(h->order_grid, N); DA(h->bin_of, N); DA(h->slot_idx, N);
+    DA(h->ccount, h->ncell); DA(h->cstart, h->ncell + 1); DA(h->cfill, h->ncell);
+    DA(h->gcount, h->gridg.nbins); DA(h->gstart, h->gridg.nbins + 1); DA(h->gfill, h->gridg.nbins);
+    {
+        const int nb = std::max(h->ncell, h->gridg.nbins);
+        DA(h->scan_tmp, nb / 2048 + 2);
+    }
+    h->gq.assign(L, nullptr); h->ge.assign(L, nullptr); h->dK.assign(L, nullptr); h->dKt.assign(L, nullptr);
+    for (int l = 0; l < L; l++) {
+        const size_t n = (size_t)h->hp.Ml[l][0] * h->hp.Ml[l][1] * h->hp.Ml[l][2];
+        DA(h->gq[l], n); DA(h->ge[l], n);
+        HIPCHK(hipMemset(h->gq[l], 0, n * sizeof(double)));
+        HIPCHK(hipMemset(h->ge[l], 0, n * sizeof(double)));
+        const LevelStencil &S = h->hp.K[l];
+        DA(h->dK[l], S.v.size()); DA(h->dKt[l], S.v.size());
+        HIPCHK(hipMemcpy(h->dK[l], S.v.data(), S.v.size() * sizeof(double), hipMemcpyHostToDevice));
+        // transposed copy [sy][sx][sz] for the tiled kernel (z taps contiguous)
+        std::vector<double> t(S.v.size());
+        for (int sz = 0; sz < S.size[2]; sz++)
+            for (int sy = 0; sy < S.size[1]; sy++)
+                for (int sx = 0; sx < S.size[0]; sx++)
+                    t[((size_t)sy * S.size[0] + sx) * S.size[2] + sz] = S.v[((size_t)sz * S.size[1] + sy) * S.size[0] + sx];
+        HIPCHK(hipMemcpy(h->dKt[l], t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    {
+        const size_t nL = h->hp.KL.v.size(), n0 = (size_t)d.M[0] * d.M[1] * d.M[2];
+        DA(h->efour, nL); DA(h->dKL, nL);
+        HIPCHK(hipMemset(h->efour, 0, nL * sizeof(double)));
+        HIPCHK(hipMemcpy(h->dKL, h->hp.KL.v.data(), nL * sizeof(double), hipMemcpyHostToDevice));
+        DA(h->tmpA, n0 / 2 + 1); DA(h->tmpB, n0 / 4 + 1);
+    }
+    h->nepart = h->small_box ? (N + 63) / 64 : h->ncell;
+    DA(h->epart, h->nepart);
+    DA(h->parts, 4 * NPARTS);
+    DA(h->d_energies, MSM_AMD_U_COUNT);
+    HIPCHK(hipHostMalloc((void **)&h->h_energies, MSM_AMD_U_COUNT * sizeof(double), hipHostMallocDefault));
+#undef DA
+    for (int i = 0; i < T_COUNT; i++) h->last_ms[i] = 0.0;
+    *out = h;
+    return MSM_AMD_OK;
+}
+
+extern "C" int msm_amd_create(const msm_amd_plan_desc *plan, int device, void *stream, msm_amd_handle **out) {
+    return create_impl(plan, false, device, stream, out);
+}
+// literal-mode handle (msmperiodic() in literal mode and the parity tests of that mode)
+extern "C" int msm_amd_create_literal(const msm_amd_plan_desc *plan, int device, void *stream, msm_amd_handle **out) {
+    return create_impl(plan, true, device, stream, out);
+}
+
+extern "C" void msm_amd_destroy(msm_amd_handle *h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    hipFree(h->ps_cell); hipFree(h->ps_grid); hipFree(h->order_cell); hipFree(h->order_grid); hipFree(h->bin_of);
+    hipFree(h->slot_idx); hipFree(h->ccount); hipFree(h->cstart); hipFree(h->cfill); hipFree(h->gcount); hipFree(h->gstart);
+    hipFree(h->gfill); hipFree(h->scan_tmp);
+    for (auto p : h->gq) hipFree(p);
+    for (auto p : h->ge) hipFree(p);
+    for (auto p : h->dK) hipFree(p);
+    for (auto p : h->dKt) hipFree(p);
+    hipFree(h->efour); hipFree(h->dKL); hipFree(h->tmpA); hipFree(h->tmpB); hipFree(h->epart); hipFree(h->parts);
+    hipFree(h->d_energies);
+    if (h->h_energies) hipHostFree(h->h_energies);
+    hipFree(h->s_r); hipFree(h->s_q); hipFree(h->s_acc);
+    if (h->ev_made) for (int i = 0; i <= T_COUNT; i++) hipEventDestroy(h->ev[i]);
+    delete h;
+}
+
+extern "C" void msm_amd_set_profiling(msm_amd_handle *h, int on) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (on && !h->ev_made) {
+        for (int i = 0; i <= T_COUNT; i++) hipEventCreate(&h->ev[i]);
+        h->ev_made = true;
+    }
+    h->profiling = on != 0;
+}
+
+extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value) {
+    if (!h || !key) return MSM_AMD_EINVAL;
+    if (!strcmp(key, "pair_variant")) { h->opt_pair_variant = value; return MSM_AMD_OK; }
+    if (!strcmp(key, "conv_tiled")) { h->opt_conv_tiled = value; return MSM_AMD_OK; }
+    set_error("unknown option %s", key);
+    return MSM_AMD_EINVAL;
+}
+
+static inline void mark(msm_amd_handle *h, int slot) {
+    if (h->profiling) hipEventRecord(h->ev[slot], h->stream);
+}
+
+extern "C" int msm_amd_stage_bin(msm_amd_handle *h, const double *d_r, const double *d_q) {
+    if (!h || !d_r || !d_q) { set_error("stage_bin: null argument"); return MSM_AMD_EINVAL; }
+    h->cur_r = d_r;
+    h->cur_q = d_q;
+    if (!h->small_box)
+        launch_bin(h->stream, d_r, d_q, h->N, h->cellg, h->bin_of, h->ccount, h->cstart, h->cfill, h->slot_idx, h->scan_tmp,
+                   h->order_cell, h->ps_cell);
+    launch_bin(h->stream, d_r, d_q, h->N, h->gridg, h->bin_of, h->gcount, h->gstart, h->gfill, h->slot_idx, h->scan_tmp,
+               h->order_grid, h->ps_grid);
+    HIPCHK(hipGetLastError());
+    return MSM_AMD_OK;
+}
+
+extern "C" int msm_amd_stage_pairs(msm_amd_handle *h, double *d_acc) {
+    if (!h || !d_acc || !h->cur_r) { set_error("stage_pairs: bin first"); return MSM_AMD_EINVAL; }
+    if (h->small_box) {
+        int n = 0;
+        launch_pair_allimages(h->stream, h->cur_r, h->cur_q, h->N, h->pp, d_acc, h->epart, &n);
+        h->nepart = n;
+    } else {
+        launch_pair_cells(h->stream, h->ps_cell, h->cstart, h->order_cell, h->ncell, h->pp, d_acc, h->epart,
+                          h->opt_pair_variant);
+        h->nepart = h->ncell;
+    }
+    HIPCHK(hipGetLastError());
+    return MSM_AMD_OK;
+}
+
+extern "C" int msm_amd_stage_anterpolate(msm_amd_handle *h) {
+    if (!h || !h->cur_r) { set_error("stage_anterpolate: bin first"); return MSM_AMD_EINVAL; }
+    launch_anterp(h->stream, h->ps_grid, h->gstart, h->sp, h->gq[0]);
+    HIPCHK(hipGetLastError());
+    return MSM_AMD_OK;
+}
+
+static void convolve_level(msm_amd_handle *h, int l, const double *q, double *e, int z0, int nz) {
+    const LevelStencil &S = h->hp.K[l];
+    if (h->hp.literal) {
+        launch_conv_literal(h->stream, q, h->dK[l], h->hp.Ml[l], S.size, S.first, e);
+        return;
+    }
+    // the tiled kernel pays off once the grid is much larger than the stencil
+    const bool big = h->hp.Ml[l][0] >= 16 && h->hp.Ml[l][1] >= 8 && nz >= 8;
+    if (h->opt_conv_tiled && big && launch_conv_tiled(h->stream, q, h->dKt[l], h->hp.Ml[l], S.size, S.first, e, z0, nz)) return;
+    launch_conv_direct(h->stream, q, h->dK[l], h->hp.Ml[l], S.size, S.first, e, z0, nz, 0);
+}
+
+extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
+    if (!h) return MSM_AMD_EINVAL;
+    const msm_amd_plan_desc &d = h->hp.d;
+    const int L = d.L, p = d.p;
+    hipStream_t st = h->stream;
+    mark(h, T_RES);
+    for (int l = 0; l + 1 < L; l++) {
+        int m0[3] = {h->hp.Ml[l][0], h->hp.Ml[l][1], h->hp.Ml[l][2]};
+        launch_restrict_axis(st, h->gq[l], h->tmpA, m0, 0, p, h->hp.J);
+        int m1[3] = {m0[0] / 2, m0[1], m0[2]};
+        launch_restrict_axis(st, h->tmpA, h->tmpB, m1, 1, p, h->hp.J);
+        int m2[3] = {m0[0] / 2, m0[1] / 2, m0[2]};
+        launch_restrict_axis(st, h->tmpB, h->gq[l + 1], m2, 2, p, h->hp.J);
+    }
+    mark(h, T_CONV);
+    for (int l = 0; l < L; l++) {
+        if (l == 0 && d.nzplanes < d.M[2]) {
+            // slab rank: level-0 potentials are needed on the owned planes plus p/2 planes either side
+            // (interpolation support); other planes of ge[0] are left untouched.
+            const int hz = p / 2, Mz = d.M[2];
+            int lo = d.zplane0 - hz, n = d.nzplanes + 2 * hz;
+            if (n >= Mz) { convolve_level(h, 0, h->gq[0], h->ge[0], 0, Mz); }
+            else {
+                lo = ((lo % Mz) + Mz) % Mz;
+                const int first = std::min(n, Mz - lo);
+                convolve_level(h, 0, h->gq[0], h->ge[0], lo, first);
+                if (n > first) convolve_level(h, 0, h->gq[0], h->ge[0], 0, n - first);
+            }
+        } else {
+            convolve_level(h, l, h->gq[l], h->ge[l], 0, h->hp.Ml[l][2]);
+        }
+    }
+    mark(h, T_TOP);
+    {
+        const int *ML = h->hp.Ml[L - 1];
+        const size_t nL = (size_t)ML[0] * ML[1] * ML[2];
+        if (h->hp.literal) {
+            // sL spans one full period on every axis (msmPeriodic.c:344-391), same index arithmetic as above
+            launch_conv_literal(st, h->gq[L - 1], h->dKL, ML, h->hp.KL.size, h->hp.KL.first, h->efour);
+            // the reference then overwrites elng with edir (msmPeriodic.c:1006-1011): nothing is added
+        } else {
+            launch_conv_direct(st, h->gq[L - 1], h->dKL, ML, h->hp.KL.size, h->hp.KL.first, h->efour, 0, ML[2], 0);
+            launch_axpy(st, h->ge[L - 1], h->efour, nL);
+        }
+    }
+    mark(h, T_PRO);
+    for (int l = L - 2; l >= 0; l--) {
+        int c0[3] = {h->hp.Ml[l + 1][0], h->hp.Ml[l + 1][1], h->hp.Ml[l + 1][2]};
+        launch_prolong_axis(st, h->ge[l + 1], h->tmpB, c0, 2, p, h->hp.J, 0);
+        int c1[3] = {c0[0], c0[1], c0[2] * 2};
+        launch_prolong_axis(st, h->tmpB, h->tmpA, c1, 1, p, h->hp.J, 0);
+        int c2[3] = {c0[0], c0[1] * 2, c0[2] * 2};
+        launch_prolong_axis(st, h->tmpA, h->ge[l], c2, 0, p, h->hp.J, 1);
+    }
+    HIPCHK(hipGetLastError());
+    return MSM_AMD_OK;
+}
+
+extern "C" int msm_amd_stage_interpolate(msm_amd_handle *h, double *d_acc) {
+    if (!h || !d_acc || !h->cur_r) { set_error("stage_interpolate: bin first"); return MSM_AMD_EINVAL; }
+    // literal: grid index = node + p/2 - 1 (msmPeriodic.c:1136-1151)
+    const int shift = h->hp.literal ? h->hp.d.p / 2 - 1 : 0;
+    launch_interp(h->stream, h->ps_grid, h->order_grid, h->N, h->sp, h->ge[0], shift, d_acc);
+    HIPCHK(hipGetLastError());
+    return MSM_AMD_OK;
+}
+
+static int queue_energies(msm_amd_handle *h) {
+    const msm_amd_plan_desc &d = h->hp.d;
+    const int L = d.L;
+    const size_t plane = (size_t)d.M[0] * d.M[1];
+    const size_t nL = (size_t)h->hp.Ml[L - 1][0] * h->hp.Ml[L - 1][1] * h->hp.Ml[L - 1][2];
+    double *pg = h->parts, *pf = h->parts + NPARTS, *pc = h->parts + 2 * NPARTS;
+    launch_dot_partials(h->stream, h->gq[0] + plane * d.zplane0, h->ge[0] + plane * d.zplane0, plane * d.nzplanes, pg, NPARTS);
+    launch_dot_partials(h->stream, h->gq[L - 1], h->efour, nL, pf, NPARTS);
+    launch_charge_partials(h->stream, h->cur_q, (size_t)h->n_owned, pc, NPARTS);
+    EnergyInputs in;
+    in.pair_parts = h->epart; in.n_pair = h->nepart;
+    in.grid_parts = pg; in.n_grid = NPARTS;
+    in.four_parts = pf; in.n_four = NPARTS;
+    in.charge_parts = pc; in.n_charge = NPARTS;
+    in.self_image_sum = h->hp.self_image_sum;
+    in.csr = h->hp.csr;
+    in.gamma0_over_a = h->hp.gamma0 / d.a;
+    in.literal = h->hp.literal ? 1 : 0;
+    launch_finalize_energies(h->stream, in, h->d_energies);
+    HIPCHK(hipGetLastError());
+    return MSM_AMD_OK;
+}
+
+extern "C" int msm_amd_stage_energies(msm_amd_handle *h, double *energies) {
+    if (!h || !h->cur_q) { set_error("stage_energies: bin first"); return MSM_AMD_EINVAL; }
+    int rc = queue_energies(h);
+    if (rc) return rc;
+    if (energies) {
+        HIPCHK(hipMemcpyAsync(h->h_energies, h->d_energies, MSM_AMD_U_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        memcpy(energies, h->h_energies, MSM_AMD_U_COUNT * sizeof(double));
+    }
+    return MSM_AMD_OK;
+}
+
+extern "C" int msm_amd_eval(msm_amd_handle *h, const double *d_r, const double *d_q, double *d_acc, double *energies) {
+    if (!h || !d_r || !d_q || !d_acc) { set_error("msm_amd_eval: null argument"); return MSM_AMD_EINVAL; }
+    HIPCHK(hipSetDevice(h->device));
+    int rc;
+    mark(h, T_BIN);
+    if ((rc = msm_amd_stage_bin(h, d_r, d_q))) return rc;
+    mark(h, T_PAIR);
+    if ((rc = msm_amd_stage_pairs(h, d_acc))) return rc;
+    mark(h, T_ANT);
+    if ((rc = msm_amd_stage_anterpolate(h))) return rc;
+    if ((rc = msm_amd_stage_grid(h))) return rc; // marks T_RES..T_PRO
+    mark(h, T_INT);
+    if ((rc = msm_amd_stage_interpolate(h, d_acc))) return rc;
+    mark(h, T_RED);
+    if ((rc = queue_energies(h))) return rc;
+    mark(h, T_TOTAL);
+    if (energies) {
+        HIPCHK(hipMemcpyAsync(h->h_energies, h->d_energies, MSM_AMD_U_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        memcpy(energies, h->h_energies, MSM_AMD_U_COUNT * sizeof(double));
+    }
+    if (h->profiling) {
+        HIPCHK(hipEventSynchronize(h->ev[T_TOTAL]));
+        for (int i = 0; i < T_TOTAL; i++) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]);
+            h->last_ms[i] = ms;
+        }
+        float ms = 0;
+        hipEventElapsedTime(&ms, h->ev[T_BIN], h->ev[T_TOTAL]);
+        h->last_ms[T_TOTAL] = ms;
+    }
+    return MSM_AMD_OK;
+}
+
+extern "C" int msm_amd_last_timings(msm_amd_handle *h, double ms[10]) {
+    if (!h || !ms) return MSM_AMD_EINVAL;
+    for (int i = 0; i < T_COUNT; i++) ms[i] = h->last_ms[i];
+    return MSM_AMD_OK;
+}
+
+static int ensure_staging(msm_amd_handle *h) {
+    if (h->s_r) return MSM_AMD_OK;
+    int rc;
+    if ((rc = dalloc(&h->s_r, 3 * (size_t)h->N))) return rc;
+    if ((rc = dalloc(&h->s_q, (size_t)h->N))) return rc;
+    if ((rc = dalloc(&h->s_acc, 3 * (size_t)h->N))) return rc;
+    return MSM_AMD_OK;
+}
+
+extern "C" int msm_amd_eval_host(msm_amd_handle *h, const double *r, const double *q, double *acc, double *energies) {
+    if (!h || !r || !q || !acc) { set_error("msm_amd_eval_host: null argument"); return MSM_AMD_EINVAL; }
+    HIPCHK(hipSetDevice(h->device));
+    int rc = ensure_staging(h);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h->s_r, r, 3 * (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->s_q, q, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if ((rc = msm_amd_eval(h, h->s_r, h->s_q, h->s_acc, energies))) return rc;
+    HIPCHK(hipMemcpyAsync(acc, h->s_acc, 3 * (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MSM_AMD_OK;
+}
+
+// ---- state access ----
+static double *grid_ptr(msm_amd_handle *h, int which, int level) {
+    if (!h) return nullptr;
+    if (which == MSM_AMD_GRID_EFOUR) return h->efour;
+    if (level < 0 || level >= h->hp.d.L) return nullptr;
+    return which == MSM_AMD_GRID_Q ? h->gq[level] : (which == MSM_AMD_GRID_E ? h->ge[level] : nullptr);
+}
+extern "C" void *msm_amd_grid_device_ptr(msm_amd_handle *h, int which, int level) { return grid_ptr(h, which, level); }
+extern "C" int msm_amd_grid_dims(msm_amd_handle *h, int level, int dims[3]) {
+    if (!h || level < 0 || level >= h->hp.d.L) return MSM_AMD_EINVAL;
+    for (int k = 0; k < 3; k++) dims[k] = h->hp.Ml[level][k];
+    return MSM_AMD_OK;
+}
+static size_t grid_count(msm_amd_handle *h, int which, int level) {
+    const int l = which == MSM_AMD_GRID_EFOUR ? h->hp.d.L - 1 : level;
+    return (size_t)h->hp.Ml[l][0] * h->hp.Ml[l][1] * h->hp.Ml[l][2];
+}
+extern "C" int msm_amd_copy_grid(msm_amd_handle *h, int which, int level, double *host_out) {
+    double *p = grid_ptr(h, which, level);
+    if (!p || !host_out) { set_error("copy_grid: bad grid selector"); return MSM_AMD_EINVAL; }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(host_out, p, grid_count(h, which, level) * sizeof(double), hipMemcpyDeviceToHost));
+    return MSM_AMD_OK;
+}
+extern "C" int msm_amd_set_grid(msm_amd_handle *h, int which, int level, const double *host_in) {
+    double *p = grid_ptr(h, which, level);
+    if (!p || !host_in) { set_error("set_grid: bad grid selector"); return MSM_AMD_EINVAL; }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(p, host_in, grid_count(h, which, level) * sizeof(double), hipMemcpyHostToDevice));
+    return MSM_AMD_OK;
+}
+extern "C" int msm_amd_stencil_info(msm_amd_handle *h, int level, int size[3], int first[3]) {
+    if (!h || level < 0 || level > h->hp.d.L) return MSM_AMD_EINVAL;
+    const LevelStencil &S = level == h->hp.d.L ? h->hp.KL : h->hp.K[level];
+    for (int k = 0; k < 3; k++) { size[k] = S.size[k]; first[k] = S.first[k]; }
+    return MSM_AMD_OK;
+}
+extern "C" int msm_amd_copy_stencil(msm_amd_handle *h, int level, double *host_out) {
+    if (!h || level < 0 || level > h->hp.d.L || !host_out) return MSM_AMD_EINVAL;
+    const LevelStencil &S = level == h->hp.d.L ? h->hp.KL : h->hp.K[level];
+    memcpy(host_out, S.v.data(), S.v.size() * sizeof(double));
+    return MSM_AMD_OK;
+}
+extern "C" int msm_amd_copy_wprime(msm_amd_handle *h, double *host_out, int *len) {
+    if (!h || !len) return MSM_AMD_EINVAL;
+    *len = (int)h->hp.wprime.size();
+    if (host_out) memcpy(host_out, h->hp.wprime.data(), h->hp.wprime.size() * sizeof(double));
+    return MSM_AMD_OK;
+}
+extern "C" int msm_amd_op_restrict(msm_amd_handle *h, int l, const double *d_fine, double *d_coarse) {
+    if (!h || l < 0 || l + 1 >= h->hp.d.L) { set_error("op_restrict: level out of range"); return MSM_AMD_EINVAL; }
+    int m0[3] = {h->hp.Ml[l][0], h->hp.Ml[l][1], h->hp.Ml[l][2]};
+    launch_restrict_axis(h->stream, d_fine, h->tmpA, m0, 0, h->hp.d.p, h->hp.J);
+    int m1[3] = {m0[0] / 2, m0[1], m0[2]};
+    launch_restrict_axis(h->stream, h->tmpA, h->tmpB, m1, 1, h->hp.d.p, h->hp.J);
+    int m2[3] = {m0[0] / 2, m0[1] / 2, m0[2]};
+    launch_restrict_axis(h->stream, h->tmpB, d_coarse, m2, 2, h->hp.d.p, h->hp.J);
+    HIPCHK(hipGetLastError());
+    return MSM_AMD_OK;
+}
+extern "C" int msm_amd_op_prolong_add(msm_amd_handle *h, int l, const double *d_coarse, double *d_fine) {
+    if (!h || l < 0 || l + 1 >= h->hp.d.L) { set_error("op_prolong_add: level out of range"); return MSM_AMD_EINVAL; }
+    int c0[3] = {h->hp.Ml[l + 1][0], h->hp.Ml[l + 1][1], h->hp.Ml[l + 1][2]};
+    launch_prolong_axis(h->stream, d_coarse, h->tmpB, c0, 2, h->hp.d.p, h->hp.J, 0);
+    int c1[3] = {c0[0], c0[1], c0[2] * 2};
+    launch_prolong_axis(h->stream, h->tmpB, h->tmpA, c1, 1, h->hp.d.p, h->hp.J, 0);
+    int c2[3] = {c0[0], c0[1] * 2, c0[2] * 2};
+    launch_prolong_axis(h->stream, h->tmpA, d_fine, c2, 0, h->hp.d.p, h->hp.J, 1);
+    HIPCHK(hipGetLastError());
+    return MSM_AMD_OK;
+}
+extern "C" int msm_amd_op_convolve(msm_amd_handle *h, int l, const double *d_q, double *d_e) {
+    if (!h || l < 0 || l > h->hp.d.L) { set_error("op_convolve: level out of range"); return MSM_AMD_EINVAL; }
+    if (l == h->hp.d.L) {
+        const int *ML = h->hp.Ml[l - 1];
+        launch_conv_direct(h->stream, d_q, h->dKL, ML, h->hp.KL.size, h->hp.KL.first, d_e, 0, ML[2], 0);
+    } else {
+        convolve_level(h, l, d_q, d_e, 0, h->hp.Ml[l][2]);
+    }
+    HIPCHK(hipGetLastError());
+    return MSM_AMD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// drop-in entry points
+// ---------------------------------------------------------------------------
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static void write_acc_file(const char *name, int N, const double *f) { // msmPeriodic.c:1369-1381
+    FILE *fp = fopen(name, "w");
+    if (!fp) return;
+    fprintf(fp, "%d\n", N);
+    for (int d = 0; d < 3; d++)
+        for (int i = 0; i < N; i++) fprintf(fp, "%20.14e\n", f[3 * i + d]);
+    fclose(fp);
+}
+
+extern "C" msm_stats msmperiodic(int N, double *r, double *q, int p, double abar, int mu, double *uappr, double *fappr,
+                                 double Ax, double Ay, double Az) {
+    msm_stats S;
+    memset(&S, 0, sizeof(S));
+    const double t_total = now_s();
+    S.N = N;
+    S.p = p;
+    const bool literal = g_mode == MSM_AMD_MODE_LITERAL || (g_mode == MSM_AMD_MODE_AUTO && N <= 4096);
+    if (literal && p != 4) { // msmPeriodic.c:100-104
+        fprintf(stderr, "p must be 4\n");
+        return S;
+    }
+    double t0 = now_s();
+    if (literal)
+        for (int i = 0; i < 3 * N; i++) r[i] += 0.5; // msmPeriodic.c:75-76: the caller's array is shifted
+    msm_amd_plan_desc d;
+    int rc = msm_amd_plan_auto(N, Ax, Ay, Az, p, mu, abar, literal ? 1 : 0, &d);
+    if (rc) { fprintf(stderr, "msmperiodic: %s\n", msm_amd_last_error()); return S; }
+    d.acc_convention = literal ? MSM_AMD_ACC_LITERAL : MSM_AMD_ACC_GRADIENT;
+    S.cputime_initialization = now_s() - t0;
+    t0 = now_s();
+    msm_amd_handle *h = nullptr;
+    rc = create_impl(&d, literal, 0, nullptr, &h);
+    if (rc) { fprintf(stderr, "msmperiodic: %s\n", msm_amd_last_error()); return S; }
+    S.cputime_stencill = now_s() - t0; // stencil generation dominates plan creation
+    const HostPlan &hp = h->hp;
+    const int L = d.L;
+
+    // parameters (msmPeriodic.c:128-335)
+    S.L = L; S.mu = mu; S.h = std::pow(Ax * Ay * Az / N, 1.0 / 3.0);
+    S.hx = hp.hl[0][0]; S.hy = hp.hl[0][1]; S.hz = hp.hl[0][2];
+    S.a = d.a; S.aL = std::pow(2, L) * d.a; S.alpha = abar; S.beta = d.beta; S.s = p - 1; S.kmax = d.kmax;
+    S.csr = hp.csr;
+    S.chinx = S.chiny = S.chinz = 2 * d.kmax + 1;
+    S.chisize = S.chinx * S.chiny * S.chinz;
+    S.rminx = S.rminy = S.rminz = 0.0; S.rmaxx = S.rmaxy = S.rmaxz = 1.0; // msmPeriodic.c:124-133
+    S.Ax = (int)Ax; S.Ay = (int)Ay; S.Az = (int)Az;
+    S.volume = Ax * Ay * Az;
+    S.Mx = d.M[0]; S.My = d.M[1]; S.Mz = d.M[2];
+    S.Mlx[0] = d.M[0]; S.Mly[0] = d.M[1]; S.Mlz[0] = d.M[2];
+    for (int l = 1; l <= L && l < LMAX; l++) { // msmPeriodic.c:184-188
+        S.Mlx[l] = (int)(d.M[0] / std::pow(2, l - 1)); S.Mly[l] = (int)(d.M[1] / std::pow(2, l - 1));
+        S.Mlz[l] = (int)(d.M[2] / std::pow(2, l - 1));
+    }
+    S.MLx = hp.Ml[L - 1][0]; S.MLy = hp.Ml[L - 1][1]; S.MLz = hp.Ml[L - 1][2];
+    S.ML2x = S.MLx / 2; S.ML2y = S.MLy / 2; S.ML2z = S.MLz / 2;
+    // print_stats reads clen = ML/2+1 entries of cvec although kmax+1 exist (msmLibrary.c:321-332): allocate the larger
+    {
+        const int need = std::max(d.kmax + 1, std::max(S.ML2x, std::max(S.ML2y, S.ML2z)) + 1);
+        double **dst[3] = {&S.cvecx, &S.cvecy, &S.cvecz};
+        for (int k = 0; k < 3; k++) {
+            *dst[k] = (double *)calloc(need, sizeof(double));
+            memcpy(*dst[k], hp.cvec[k].data(), hp.cvec[k].size() * sizeof(double));
+        }
+        S.clenx = S.ML2x + 1; S.cleny = S.ML2y + 1; S.clenz = S.ML2z + 1;
+        S.chi = (double *)calloc(S.chisize, sizeof(double));
+        memcpy(S.chi, hp.chi.data(), hp.chi.size() * sizeof(double));
+        S.chisum = hp.chisum;
+    }
+    S.sLnx = 2 * (S.MLx - 1) + 1; S.sLny = 2 * (S.MLy - 1) + 1; S.sLnz = 2 * (S.MLz - 1) + 1;
+    S.sLsize = S.sLnx * S.sLny * S.sLnz;
+    for (int l = 0; l < L; l++) {
+        S.slsizex[l] = hp.K[l].size[0]; S.slsizey[l] = hp.K[l].size[1]; S.slsizez[l] = hp.K[l].size[2];
+    }
+    if (literal && !g_quiet) { // msmPeriodic.c:600-610
+        const LevelStencil &K = hp.K[0];
+        printf("Stencil[%d]\n", 0);
+        for (int nz = 0; nz < K.size[2]; nz++)
+            for (int ny = 0; ny < K.size[1]; ny++)
+                for (int nx = 0; nx < K.size[0]; nx++)
+                    printf("%2d x %2d x %2d %25.16f \n", nz - 1, ny - 1, nx - 1,
+                           K.v[((size_t)nz * K.size[1] + ny) * K.size[0] + nx]);
+    }
+
+    // evaluation, stage by stage so that the two acceleration parts can be reported separately
+    std::vector<double> fs(3 * (size_t)N), fl(3 * (size_t)N), g0((size_t)d.M[0] * d.M[1] * d.M[2]);
+    double en[MSM_AMD_U_COUNT];
+    double *dr = nullptr, *dq = nullptr, *dfs = nullptr, *dfl = nullptr;
+    bool ok = dalloc(&dr, 3 * (size_t)N) == 0 && dalloc(&dq, (size_t)N) == 0 && dalloc(&dfs, 3 * (size_t)N) == 0 &&
+              dalloc(&dfl, 3 * (size_t)N) == 0;
+    if (ok) {
+        hipMemcpy(dr, r, 3 * (size_t)N * sizeof(double), hipMemcpyHostToDevice);
+        hipMemcpy(dq, q, (size_t)N * sizeof(double), hipMemcpyHostToDevice);
+        hipMemset(dfl, 0, 3 * (size_t)N * sizeof(double));
+        auto tick = [&](double &slot, int rc_) { hipStreamSynchronize(h->stream); slot = now_s() - t0; t0 = now_s(); return rc_; };
+        double tbin;
+        t0 = now_s();
+        ok = ok && !tick(tbin, msm_amd_stage_bin(h, dr, dq));
+        ok = ok && !tick(S.cputime_anterpolation, msm_amd_stage_anterpolate(h));
+        ok = ok && !tick(S.cputime_grid_to_grid_mapping, msm_amd_stage_grid(h));
+        ok = ok && !tick(S.cputime_interpolation, msm_amd_stage_interpolate(h, dfl));
+        ok = ok && !tick(S.cputime_short_range, msm_amd_stage_pairs(h, dfs));
+        ok = ok && !tick(S.cputime_potential_long, msm_amd_stage_energies(h, en));
+        if (ok) {
+            hipMemcpy(fs.data(), dfs, fs.size() * sizeof(double), hipMemcpyDeviceToHost);
+            hipMemcpy(fl.data(), dfl, fl.size() * sizeof(double), hipMemcpyDeviceToHost);
+            msm_amd_copy_grid(h, MSM_AMD_GRID_Q, 0, g0.data());
+        }
+    }
+    hipFree(dr); hipFree(dq); hipFree(dfs); hipFree(dfl);
+    if (!ok) {
+        fprintf(stderr, "msmperiodic: %s\n", msm_amd_last_error());
+        msm_amd_destroy(h);
+        return S;
+    }
+    if (literal && !g_quiet) { // msmPeriodic.c:723-733
+        printf("grid charge at first level\n");
+        for (size_t i = 0; i < g0.size(); i++) printf("%25.16e\n", g0[i]);
+    }
+    S.potential_short_real = en[MSM_AMD_U_SHORT_REAL];
+    S.potential_short_self = en[MSM_AMD_U_SHORT_SELF];
+    S.potential_short_csr = en[MSM_AMD_U_SHORT_CSR];
+    S.potential_short_total = en[0] + en[1] + en[2];
+    S.potential_long_real = en[MSM_AMD_U_LONG_REAL];
+    S.potential_long_fourier = en[MSM_AMD_U_LONG_FOUR];
+    S.potential_long_self = en[MSM_AMD_U_LONG_SELF];
+    S.potential_long_total = en[MSM_AMD_U_LONG_FOUR] + en[MSM_AMD_U_LONG_REAL] + en[MSM_AMD_U_LONG_SELF];
+    S.potential_total = en[MSM_AMD_U_TOTAL];
+    if (uappr) *uappr = S.potential_total;
+    for (size_t i = 0; i < fs.size(); i++) fappr[i] = fs[i] + fl[i]; // msmPeriodic.c:1362-1367
+    if (literal && !g_quiet) {
+        write_acc_file("msm.acclong", N, fl.data());
+        write_acc_file("msm.accshort", N, fs.data());
+    }
+    {
+        double qs = 0.0, gs = 0.0;
+        for (int i = 0; i < N; i++) qs += q[i];
+        for (size_t i = 0; i < g0.size(); i++) gs += g0[i];
+        S.netcharge = qs;
+        S.netgridcharge[0] = gs;
+    }
+    msm_amd_destroy(h);
+    S.cputime_total = now_s() - t_total;
+    return S;
+}
+
+extern "C" double msmPeriodicRunner(double *r, double *q, double *force, int n, int p, int mu, double abar, double Lx,
+                                    double Ly, double Lz) {
+    double potential = 0.0;
+    msm_stats st = msmperiodic(n, r, q, p, abar, mu, &potential, force, Lx, Ly, Lz);
+    print_stats(st);
+    return st.potential_total;
+}

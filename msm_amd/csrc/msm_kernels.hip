@@ -1,0 +1,903 @@
+// gfx950 (MI355X) kernels of the MSM hot path.  All arithmetic is FP64.
+//
+//   binning        k_bin_*            counting sort, deterministic order inside a bin
+//   short range    k_pair_cells       cell list, LDS-staged neighbour tiles (msmLibrary.c:125-182 batched)
+//                  k_pair_allimages   small boxes: every pair, every image inside the cutoff
+//   anterpolation  k_anterp_gather    one thread per grid node gathers its particles (msmPeriodic.c:688-717)
+//   restriction    k_restrict_axis    separable, one axis per pass (msmPeriodic.c:754-838)
+//   convolution    k_conv_direct / k_conv_tiled / k_conv_literal (msmPeriodic.c:846-918, 936-998)
+//   prolongation   k_prolong_axis     separable (msmPeriodic.c:1018-1108)
+//   interpolation  k_interp           one thread per particle (msmPeriodic.c:1116-1161)
+//   reductions     k_dot_partials, k_charge_partials, k_finalize_energies (msmPeriodic.c:1305-1359)
+#include "msm_kernels.hpp"
+
+#include "msm_amd.h"
+
+namespace msm {
+
+// Blocks b and b+8 share an XCD (and its L2).  Give each XCD a contiguous run of
+// logical ids so that neighbouring tiles / cells, which share halo data, meet in one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, k = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+__device__ __forceinline__ int wrap1(int i, int M) { // i in [-M, 2M)
+    i = (i < 0) ? i + M : i;
+    return (i >= M) ? i - M : i;
+}
+__device__ __forceinline__ int modp(int i, int M) {
+    int r = i % M;
+    return r < 0 ? r + M : r;
+}
+
+// ---------------------------------------------------------------------------
+// binning
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void frac_coords(const double *__restrict__ r, int i, const BinGeom &g, double s[3]) {
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        double t = r[3 * (size_t)i + d] * g.invA[d];
+        t -= floor(t);
+        s[d] = t;
+    }
+}
+__device__ __forceinline__ int bin_index(const double s[3], const BinGeom &g) {
+    int b[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        int v = (int)(s[d] * g.nb[d]);
+        b[d] = v >= g.nb[d] ? g.nb[d] - 1 : v;
+    }
+    return (b[2] * g.nb[1] + b[1]) * g.nb[0] + b[0];
+}
+
+__global__ void k_bin_count(const double *__restrict__ r, int N, BinGeom g, int *__restrict__ bin_of, int *__restrict__ count) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double s[3];
+    frac_coords(r, i, g, s);
+    int b = bin_index(s, g);
+    bin_of[i] = b;
+    atomicAdd(&count[b], 1);
+}
+
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 8
+#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
+
+__global__ void k_scan_tile_sums(const int *__restrict__ in, int n, int *__restrict__ tile_sums) {
+    __shared__ int red[SCAN_THREADS];
+    int base = blockIdx.x * SCAN_TILE, s = 0;
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        int idx = base + k * SCAN_THREADS + threadIdx.x;
+        if (idx < n) s += in[idx];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = SCAN_THREADS / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = red[0];
+}
+
+// exclusive scan of tile_sums in place by one block (ntiles is small)
+__global__ void k_scan_tile_offsets(int *__restrict__ tile_sums, int ntiles) {
+    __shared__ int buf[SCAN_THREADS];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < ntiles; base += SCAN_THREADS) {
+        int idx = base + threadIdx.x;
+        int v = idx < ntiles ? tile_sums[idx] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < SCAN_THREADS; off <<= 1) {
+            int t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        int incl = buf[threadIdx.x], c = carry;
+        if (idx < ntiles) tile_sums[idx] = c + incl - v;
+        __syncthreads();
+        if (threadIdx.x == SCAN_THREADS - 1) carry = c + incl;
+        __syncthreads();
+    }
+}
+
+// out[i] = exclusive prefix of in, out[n] = total
+__global__ void k_scan_apply(const int *__restrict__ in, int n, const int *__restrict__ tile_off, int *__restrict__ out) {
+    __shared__ int buf[SCAN_THREADS];
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        s += v[k];
+    }
+    buf[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
+        int t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+        __syncthreads();
+        buf[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = tile_off[blockIdx.x] + buf[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+        if (base + k == n - 1) out[n] = run;
+    }
+}
+
+__global__ void k_bin_scatter(const int *__restrict__ bin_of, int N, const int *__restrict__ start, int *__restrict__ fill,
+                              int *__restrict__ slot_idx) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    int b = bin_of[i];
+    int s = start[b] + atomicAdd(&fill[b], 1);
+    slot_idx[s] = i;
+}
+
+// The scatter above fills a bin in arrival order.  Rank every entry by its particle index inside
+// its bin so that the stored order (hence every later summation order) is the same on every run.
+__global__ void k_bin_finalize(const double *__restrict__ r, const double *__restrict__ q, int N, BinGeom g,
+                               const int *__restrict__ bin_of, const int *__restrict__ start,
+                               const int *__restrict__ slot_idx, int *__restrict__ order, double4 *__restrict__ ps) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    int i = slot_idx[s];
+    int b = bin_of[i];
+    int st = start[b], en = start[b + 1], rank = 0;
+    for (int t = st; t < en; t++) rank += (slot_idx[t] < i);
+    double f[3];
+    frac_coords(r, i, g, f);
+    int dst = st + rank;
+    order[dst] = i;
+    ps[dst] = make_double4(f[0] * g.scale[0], f[1] * g.scale[1], f[2] * g.scale[2], q[i]);
+}
+
+void launch_bin(hipStream_t st, const double *d_r, const double *d_q, int N, const BinGeom &g, int *bin_of, int *count,
+                int *start, int *fill, int *slot_idx, int *scan_tmp, int *order, double4 *ps) {
+    const int nb = g.nbins;
+    hipMemsetAsync(count, 0, sizeof(int) * (size_t)nb, st);
+    hipMemsetAsync(fill, 0, sizeof(int) * (size_t)nb, st);
+    const int tb = 256, gb = (N + tb - 1) / tb;
+    hipLaunchKernelGGL(k_bin_count, dim3(gb), dim3(tb), 0, st, d_r, N, g, bin_of, count);
+    const int ntiles = (nb + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(SCAN_THREADS), 0, st, count, nb, scan_tmp);
+    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(SCAN_THREADS), 0, st, scan_tmp, ntiles);
+    hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(SCAN_THREADS), 0, st, count, nb, scan_tmp, start);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(gb), dim3(tb), 0, st, bin_of, N, start, fill, slot_idx);
+    hipLaunchKernelGGL(k_bin_finalize, dim3(gb), dim3(tb), 0, st, d_r, d_q, N, g, bin_of, start, slot_idx, order, ps);
+}
+
+// ---------------------------------------------------------------------------
+// short range
+// ---------------------------------------------------------------------------
+// One in-cutoff pair.  d = r_i - r_j - A p.  g0(r) = 1/r - gamma(r/a)/a;  g0'(r)/r = -1/r^3 + D(y)/a^3 with
+// D = -gamma'(rho)/rho  (msmLibrary.h:18-19 for p = 4).  Adds q_j g0 to u, q_j g0'/r d to fw and g0'/r d to fu.
+template <int P, bool UNW>
+__device__ __forceinline__ void pair_term(double dx, double dy, double dz, double r2, double qj, const PairParams &pp,
+                                          double &u, double &fwx, double &fwy, double &fwz, double &fux, double &fuy,
+                                          double &fuz) {
+    const double ir = rsqrt(r2);
+    const double y = r2 * pp.inv_a2 - 1.0;
+    double gam = pp.cg[P - 1], dg = pp.cd[P - 2];
+#pragma unroll
+    for (int k = P - 2; k >= 0; k--) gam = fma(gam, y, pp.cg[k]);
+#pragma unroll
+    for (int k = P - 3; k >= 0; k--) dg = fma(dg, y, pp.cd[k]);
+    const double g0 = ir - gam * pp.inv_a;
+    const double s = dg * pp.inv_a3 - ir * ir * ir;
+    u = fma(qj, g0, u);
+    const double qs = qj * s;
+    fwx = fma(qs, dx, fwx);
+    fwy = fma(qs, dy, fwy);
+    fwz = fma(qs, dz, fwz);
+    if (UNW) {
+        fux = fma(s, dx, fux);
+        fuy = fma(s, dy, fuy);
+        fuz = fma(s, dz, fuz);
+    }
+}
+
+__device__ __forceinline__ void store_acc(double *__restrict__ acc, int orig, int convention, double qi, double fwx,
+                                          double fwy, double fwz, double fux, double fuy, double fuz) {
+    double ox, oy, oz;
+    if (convention == MSM_AMD_ACC_LITERAL) { // msmLibrary.c:168-176 summed over both visits of a pair
+        ox = 0.5 * (qi * fux + fwx); oy = 0.5 * (qi * fuy + fwy); oz = 0.5 * (qi * fuz + fwz);
+    } else if (convention == MSM_AMD_ACC_FORCE) {
+        ox = -qi * fwx; oy = -qi * fwy; oz = -qi * fwz;
+    } else {
+        ox = fwx; oy = fwy; oz = fwz;
+    }
+    acc[3 * (size_t)orig] = ox;
+    acc[3 * (size_t)orig + 1] = oy;
+    acc[3 * (size_t)orig + 2] = oz;
+}
+
+// sum over a workgroup, result valid in thread 0
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double *red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+#pragma unroll
+    for (int off = NT / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    return red[0];
+}
+
+#define PAIR_THREADS 128
+#define PAIR_TJ 128
+
+// One workgroup per cell (edge >= a, at least 3 cells per axis so the 27 neighbours are distinct).
+// Lane = one particle of the cell; the neighbour cell's particles, already translated by the periodic
+// shift of that neighbour, are staged in LDS and read by every lane at the same address (broadcast).
+template <int P, bool UNW>
+__global__ __launch_bounds__(PAIR_THREADS) void k_pair_cells(const double4 *__restrict__ ps, const int *__restrict__ cstart,
+                                                             const int *__restrict__ order, PairParams pp,
+                                                             double *__restrict__ acc, double *__restrict__ epart) {
+    __shared__ double4 tile[PAIR_TJ];
+    __shared__ double red[PAIR_THREADS];
+    const int tid = threadIdx.x;
+    const int cell = xcd_remap(blockIdx.x, gridDim.x);
+    const int cx = cell % pp.nc[0], cy = (cell / pp.nc[0]) % pp.nc[1], cz = cell / (pp.nc[0] * pp.nc[1]);
+    const int i0 = cstart[cell], i1 = cstart[cell + 1];
+    double esum = 0.0;
+    for (int ib = i0; ib < i1; ib += PAIR_THREADS) {
+        const int ii = ib + tid;
+        const bool active = ii < i1;
+        double4 pi = active ? ps[ii] : make_double4(0, 0, 0, 0);
+        double u = 0, fwx = 0, fwy = 0, fwz = 0, fux = 0, fuy = 0, fuz = 0;
+        for (int nb = 0; nb < 27; nb++) {
+            int nx = cx + (nb % 3) - 1, ny = cy + ((nb / 3) % 3) - 1, nz = cz + (nb / 9) - 1;
+            double sx = 0, sy = 0, sz = 0;
+            if (nx < 0) { nx += pp.nc[0]; sx = -pp.A[0]; } else if (nx >= pp.nc[0]) { nx -= pp.nc[0]; sx = pp.A[0]; }
+            if (ny < 0) { ny += pp.nc[1]; sy = -pp.A[1]; } else if (ny >= pp.nc[1]) { ny -= pp.nc[1]; sy = pp.A[1]; }
+            if (nz < 0) { nz += pp.nc[2]; sz = -pp.A[2]; } else if (nz >= pp.nc[2]) { nz -= pp.nc[2]; sz = pp.A[2]; }
+            const int cn = (nz * pp.nc[1] + ny) * pp.nc[0] + nx;
+            const int j0 = cstart[cn], j1 = cstart[cn + 1];
+            for (int jb = j0; jb < j1; jb += PAIR_TJ) {
+                const int cnt = min(PAIR_TJ, j1 - jb);
+                __syncthreads();
+                if (tid < cnt) {
+                    double4 pj = ps[jb + tid];
+                    pj.x += sx; pj.y += sy; pj.z += sz;
+                    tile[tid] = pj;
+                }
+                __syncthreads();
+                if (active) {
+                    for (int k = 0; k < cnt; k++) {
+                        const double4 pj = tile[k];
+                        const double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                        const double r2 = fma(dx, dx, fma(dy, dy, dz * dz));
+                        if (r2 < pp.a2 && (jb + k) != ii)
+                            pair_term<P, UNW>(dx, dy, dz, r2, pj.w, pp, u, fwx, fwy, fwz, fux, fuy, fuz);
+                    }
+                }
+            }
+        }
+        if (active) {
+            store_acc(acc, order[ii], pp.convention, pi.w, fwx, fwy, fwz, fux, fuy, fuz);
+            esum += 0.5 * pi.w * u;
+        }
+    }
+    const double tot = block_sum<PAIR_THREADS>(esum, red);
+    if (tid == 0) epart[cell] = tot;
+}
+
+// Two-phase variant: phase 1 filters the candidates of a neighbour tile with a cheap FP64 distance test and
+// appends the survivors to a per-lane list in LDS; phase 2 runs the expensive kernel only on survivors, so
+// lanes no longer idle through the ~85 % of candidates that fall outside the cutoff.
+#define PAIR2_THREADS 64
+#define PAIR2_TJ 192
+#define PAIR2_LIST 48
+template <int P, bool UNW>
+__global__ __launch_bounds__(PAIR2_THREADS) void k_pair_cells2(const double4 *__restrict__ ps, const int *__restrict__ cstart,
+                                                               const int *__restrict__ order, PairParams pp,
+                                                               double *__restrict__ acc, double *__restrict__ epart) {
+    __shared__ double4 tile[PAIR2_TJ];
+    __shared__ unsigned char list[PAIR2_LIST][PAIR2_THREADS]; // [entry][lane]: conflict-free per-lane columns
+    __shared__ double red[PAIR2_THREADS];
+    const int tid = threadIdx.x;
+    const int cell = xcd_remap(blockIdx.x, gridDim.x);
+    const int cx = cell % pp.nc[0], cy = (cell / pp.nc[0]) % pp.nc[1], cz = cell / (pp.nc[0] * pp.nc[1]);
+    const int i0 = cstart[cell], i1 = cstart[cell + 1];
+    double esum = 0.0;
+    for (int ib = i0; ib < i1; ib += PAIR2_THREADS) {
+        const int ii = ib + tid;
+        const bool active = ii < i1;
+        double4 pi = active ? ps[ii] : make_double4(1e300, 1e300, 1e300, 0);
+        double u = 0, fwx = 0, fwy = 0, fwz = 0, fux = 0, fuy = 0, fuz = 0;
+        // the 27 neighbours form 9 rows of 3 x-adjacent cells; rows are contiguous in memory unless they wrap
+        for (int nb = 0; nb < 27; nb++) {
+            int nx = cx + (nb % 3) - 1, ny = cy + ((nb / 3) % 3) - 1, nz = cz + (nb / 9) - 1;
+            double sx = 0, sy = 0, sz = 0;
+            if (nx < 0) { nx += pp.nc[0]; sx = -pp.A[0]; } else if (nx >= pp.nc[0]) { nx -= pp.nc[0]; sx = pp.A[0]; }
+            if (ny < 0) { ny += pp.nc[1]; sy = -pp.A[1]; } else if (ny >= pp.nc[1]) { ny -= pp.nc[1]; sy = pp.A[1]; }
+            if (nz < 0) { nz += pp.nc[2]; sz = -pp.A[2]; } else if (nz >= pp.nc[2]) { nz -= pp.nc[2]; sz = pp.A[2]; }
+            const int cn = (nz * pp.nc[1] + ny) * pp.nc[0] + nx;
+            const int j0 = cstart[cn], j1 = cstart[cn + 1];
+            for (int jb = j0; jb < j1; jb += PAIR2_TJ) {
+                const int cnt = min(PAIR2_TJ, j1 - jb);
+                __syncthreads();
+                for (int t = tid; t < cnt; t += PAIR2_THREADS) {
+                    double4 pj = ps[jb + t];
+                    pj.x += sx; pj.y += sy; pj.z += sz;
+                    tile[t] = pj;
+                }
+                __syncthreads();
+                int k = 0;
+                while (k < cnt) {
+                    // phase 1: scan candidates until this lane's list is full or the tile ends
+                    int n = 0;
+                    for (; k < cnt && n < PAIR2_LIST; k++) {
+                        const double4 pj = tile[k];
+                        const double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                        const double r2 = fma(dx, dx, fma(dy, dy, dz * dz));
+                        if (r2 < pp.a2 && (jb + k) != ii) { list[n][tid] = (unsigned char)k; n++; }
+                    }
+                    // phase 2: the expensive kernel on this lane's survivors
+                    for (int e = 0; e < n; e++) {
+                        const double4 pj = tile[list[e][tid]];
+                        const double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
+                        const double r2 = fma(dx, dx, fma(dy, dy, dz * dz));
+                        pair_term<P, UNW>(dx, dy, dz, r2, pj.w, pp, u, fwx, fwy, fwz, fux, fuy, fuz);
+                    }
+                }
+            }
+        }
+        if (active) {
+            store_acc(acc, order[ii], pp.convention, pi.w, fwx, fwy, fwz, fux, fuy, fuz);
+            esum += 0.5 * pi.w * u;
+        }
+    }
+    const double tot = block_sum<PAIR2_THREADS>(esum, red);
+    if (tid == 0) epart[cell] = tot;
+}
+
+void launch_pair_cells(hipStream_t st, const double4 *ps, const int *cstart, const int *order, int ncell,
+                       const PairParams &pp, double *acc, double *epart, int variant) {
+    const bool unw = pp.convention == MSM_AMD_ACC_LITERAL;
+#define LAUNCH_PAIR(KERN, NT)                                                                                          \
+    do {                                                                                                               \
+        if (pp.p == 4) {                                                                                               \
+            if (unw) hipLaunchKernelGGL((KERN<4, true>), dim3(ncell), dim3(NT), 0, st, ps, cstart, order, pp, acc, epart); \
+            else hipLaunchKernelGGL((KERN<4, false>), dim3(ncell), dim3(NT), 0, st, ps, cstart, order, pp, acc, epart);  \
+        } else {                                                                                                       \
+            if (unw) hipLaunchKernelGGL((KERN<6, true>), dim3(ncell), dim3(NT), 0, st, ps, cstart, order, pp, acc, epart); \
+            else hipLaunchKernelGGL((KERN<6, false>), dim3(ncell), dim3(NT), 0, st, ps, cstart, order, pp, acc, epart);  \
+        }                                                                                                              \
+    } while (0)
+    if (variant == 2) LAUNCH_PAIR(k_pair_cells2, PAIR2_THREADS);
+    else LAUNCH_PAIR(k_pair_cells, PAIR_THREADS);
+#undef LAUNCH_PAIR
+}
+
+// Small boxes (fewer than 3 cells per axis): thread i visits every j and every image inside the cutoff
+// (msmPeriodic.c:1292-1300 + msmLibrary.c:141-178).  Self images belong to the (B) term and are skipped.
+#define PAIRA_THREADS 64
+template <int P, bool UNW>
+__global__ __launch_bounds__(PAIRA_THREADS) void k_pair_allimages(const double *__restrict__ r, const double *__restrict__ q,
+                                                                  int N, PairParams pp, double a,
+                                                                  double *__restrict__ acc, double *__restrict__ epart) {
+    __shared__ double red[PAIRA_THREADS];
+    const int i = blockIdx.x * PAIRA_THREADS + threadIdx.x;
+    double esum = 0.0;
+    if (i < N) {
+        const double xi = r[3 * (size_t)i], yi = r[3 * (size_t)i + 1], zi = r[3 * (size_t)i + 2], qi = q[i];
+        double u = 0, fwx = 0, fwy = 0, fwz = 0, fux = 0, fuy = 0, fuz = 0;
+        for (int j = 0; j < N; j++) {
+            if (j == i) continue;
+            const double ex = xi - r[3 * (size_t)j], ey = yi - r[3 * (size_t)j + 1], ez = zi - r[3 * (size_t)j + 2], qj = q[j];
+            const int x0 = (int)ceil((ex - a) / pp.A[0]), x1 = (int)floor((ex + a) / pp.A[0]);
+            const int y0 = (int)ceil((ey - a) / pp.A[1]), y1 = (int)floor((ey + a) / pp.A[1]);
+            const int z0 = (int)ceil((ez - a) / pp.A[2]), z1 = (int)floor((ez + a) / pp.A[2]);
+            for (int px = x0; px <= x1; px++)
+                for (int py = y0; py <= y1; py++)
+                    for (int pz = z0; pz <= z1; pz++) {
+                        const double dx = ex - pp.A[0] * px, dy = ey - pp.A[1] * py, dz = ez - pp.A[2] * pz;
+                        const double r2 = dx * dx + dy * dy + dz * dz;
+                        if (r2 < pp.a2) pair_term<P, UNW>(dx, dy, dz, r2, qj, pp, u, fwx, fwy, fwz, fux, fuy, fuz);
+                    }
+        }
+        store_acc(acc, i, pp.convention, qi, fwx, fwy, fwz, fux, fuy, fuz);
+        esum = 0.5 * qi * u;
+    }
+    const double tot = block_sum<PAIRA_THREADS>(esum, red);
+    if (threadIdx.x == 0) epart[blockIdx.x] = tot;
+}
+
+void launch_pair_allimages(hipStream_t st, const double *d_r, const double *d_q, int N, const PairParams &pp, double *acc,
+                           double *epart, int *nepart) {
+    const int nblk = (N + PAIRA_THREADS - 1) / PAIRA_THREADS;
+    const double a = sqrt(pp.a2);
+    const bool unw = pp.convention == MSM_AMD_ACC_LITERAL;
+    if (pp.p == 4) {
+        if (unw) hipLaunchKernelGGL((k_pair_allimages<4, true>), dim3(nblk), dim3(PAIRA_THREADS), 0, st, d_r, d_q, N, pp, a, acc, epart);
+        else hipLaunchKernelGGL((k_pair_allimages<4, false>), dim3(nblk), dim3(PAIRA_THREADS), 0, st, d_r, d_q, N, pp, a, acc, epart);
+    } else {
+        if (unw) hipLaunchKernelGGL((k_pair_allimages<6, true>), dim3(nblk), dim3(PAIRA_THREADS), 0, st, d_r, d_q, N, pp, a, acc, epart);
+        else hipLaunchKernelGGL((k_pair_allimages<6, false>), dim3(nblk), dim3(PAIRA_THREADS), 0, st, d_r, d_q, N, pp, a, acc, epart);
+    }
+    *nepart = nblk;
+}
+
+// ---------------------------------------------------------------------------
+// B-spline nodal basis: centred spline Phi(t) = B_p(t + p/2) and its derivative
+// (closed forms of the pieces: msmLibrary.h:120-142)
+// ---------------------------------------------------------------------------
+template <int P>
+__device__ __forceinline__ double phi_c(double t);
+template <>
+__device__ __forceinline__ double phi_c<4>(double t) {
+    const double a = fabs(t);
+    if (a >= 2.0) return 0.0;
+    if (a < 1.0) return (2.0 / 3.0) + a * a * (0.5 * a - 1.0);
+    const double b = 2.0 - a;
+    return (1.0 / 6.0) * b * b * b;
+}
+template <>
+__device__ __forceinline__ double phi_c<6>(double t) {
+    const double a = fabs(t);
+    if (a >= 3.0) return 0.0;
+    if (a < 1.0) { const double a2 = a * a; return 11.0 / 20.0 + a2 * (-0.5 + a2 * (0.25 - a * (1.0 / 12.0))); }
+    if (a < 2.0) return 17.0 / 40.0 + a * (5.0 / 8.0 + a * (-7.0 / 4.0 + a * (5.0 / 4.0 + a * (-3.0 / 8.0 + a * (1.0 / 24.0)))));
+    const double b = 3.0 - a, b2 = b * b;
+    return (1.0 / 120.0) * b2 * b2 * b;
+}
+template <int P>
+__device__ __forceinline__ double dphi_c(double t);
+template <>
+__device__ __forceinline__ double dphi_c<4>(double t) {
+    const double a = fabs(t);
+    double d;
+    if (a >= 2.0) d = 0.0;
+    else if (a < 1.0) d = a * (1.5 * a - 2.0);
+    else { const double b = 2.0 - a; d = -0.5 * b * b; }
+    return t < 0 ? -d : d;
+}
+template <>
+__device__ __forceinline__ double dphi_c<6>(double t) {
+    const double a = fabs(t);
+    double d;
+    if (a >= 3.0) d = 0.0;
+    else if (a < 1.0) { const double a2 = a * a; d = a * (-1.0 + a2 * (1.0 - a * (5.0 / 12.0))); }
+    else if (a < 2.0) d = 5.0 / 8.0 + a * (-7.0 / 2.0 + a * (15.0 / 4.0 + a * (-3.0 / 2.0 + a * (5.0 / 24.0))));
+    else { const double b = 3.0 - a, b2 = b * b; d = -(1.0 / 24.0) * b2 * b2; }
+    return t < 0 ? -d : d;
+}
+
+// Gather form of q_m = sum_i q_i sum_P Phi(M(s_i - P) - m): the thread of array element j collects every
+// particle stored in the p^3 grid bins around its node.  Bins are walked unwrapped so that a grid smaller
+// than the spline support receives every periodic image.  Particle order inside a bin is fixed, so the sum
+// is bitwise reproducible.
+template <int P>
+__global__ __launch_bounds__(256) void k_anterp_gather(const double4 *__restrict__ ps, const int *__restrict__ gstart,
+                                                       SplineParams sp, double *__restrict__ grid) {
+    const int Mx = sp.M[0], My = sp.M[1], Mz = sp.M[2];
+    const size_t nplane = (size_t)Mx * My;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nplane * sp.nz) return;
+    const int jx = (int)(idx % Mx), jy = (int)((idx / Mx) % My), jz = sp.z0 + (int)(idx / nplane);
+    double sum = 0.0;
+    const bool dropped = (sp.drop_last[0] && jx == Mx - 1) || (sp.drop_last[1] && jy == My - 1) ||
+                         (sp.drop_last[2] && jz == Mz - 1);
+    if (!dropped) {
+        const int mx = jx - sp.node_shift[0], my = jy - sp.node_shift[1], mz = jz - sp.node_shift[2];
+        for (int bz = mz - P / 2; bz < mz + P / 2; bz++) {
+            const int wz = modp(bz, Mz);
+            const double oz = (double)(bz - wz) - (double)mz;
+            for (int by = my - P / 2; by < my + P / 2; by++) {
+                const int wy = modp(by, My);
+                const double oy = (double)(by - wy) - (double)my;
+                for (int bx = mx - P / 2; bx < mx + P / 2; bx++) {
+                    const int wx = modp(bx, Mx);
+                    const double ox = (double)(bx - wx) - (double)mx;
+                    const int b = (wz * My + wy) * Mx + wx;
+                    const int s0 = gstart[b], s1 = gstart[b + 1];
+                    for (int s = s0; s < s1; s++) {
+                        const double4 pt = ps[s];
+                        sum += pt.w * phi_c<P>(pt.x + ox) * phi_c<P>(pt.y + oy) * phi_c<P>(pt.z + oz);
+                    }
+                }
+            }
+        }
+    }
+    grid[((size_t)jz * My + jy) * Mx + jx] = sum;
+}
+
+void launch_anterp(hipStream_t st, const double4 *ps_grid, const int *gstart, const SplineParams &sp, double *grid) {
+    const size_t n = (size_t)sp.M[0] * sp.M[1] * sp.nz;
+    const int tb = 256;
+    const int gb = (int)((n + tb - 1) / tb);
+    if (sp.p == 4) hipLaunchKernelGGL((k_anterp_gather<4>), dim3(gb), dim3(tb), 0, st, ps_grid, gstart, sp, grid);
+    else hipLaunchKernelGGL((k_anterp_gather<6>), dim3(gb), dim3(tb), 0, st, ps_grid, gstart, sp, grid);
+}
+
+// acc_i += sum_m e_m grad Phi_m(r_i) over the p^3 nodes around particle i (msmPeriodic.c:1116-1161,
+// msmSimple.c:1317-1380).  Particles are visited in grid-bin order, so neighbouring lanes read neighbouring
+// nodes; index_shift reproduces the reference's interpolation index offset when asked to.
+template <int P>
+__global__ __launch_bounds__(256) void k_interp(const double4 *__restrict__ ps, const int *__restrict__ order, int N,
+                                                SplineParams sp, const double *__restrict__ e, int index_shift,
+                                                double *__restrict__ acc) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    const double4 pt = ps[k];
+    const int Mx = sp.M[0], My = sp.M[1], Mz = sp.M[2];
+    double w[3][P], dw[3][P];
+    int base[3];
+    const double u[3] = {pt.x, pt.y, pt.z};
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        int fl = (int)floor(u[d]);
+        fl = fl >= sp.M[d] ? sp.M[d] - 1 : fl;
+        base[d] = fl - (P / 2 - 1);
+#pragma unroll
+        for (int v = 0; v < P; v++) {
+            const double t = u[d] - (double)(base[d] + v);
+            w[d][v] = phi_c<P>(t);
+            dw[d][v] = dphi_c<P>(t);
+        }
+    }
+    double gx = 0, gy = 0, gz = 0;
+#pragma unroll
+    for (int c = 0; c < P; c++) {
+        const int iz = modp(base[2] + c + index_shift, Mz);
+#pragma unroll
+        for (int b = 0; b < P; b++) {
+            const int iy = modp(base[1] + b + index_shift, My);
+            const double *row = e + ((size_t)iz * My + iy) * Mx;
+            const double wyz = w[1][b] * w[2][c], dyz = dw[1][b] * w[2][c], ydz = w[1][b] * dw[2][c];
+#pragma unroll
+            for (int a = 0; a < P; a++) {
+                const double ev = row[modp(base[0] + a + index_shift, Mx)];
+                gx = fma(dw[0][a] * wyz, ev, gx);
+                gy = fma(w[0][a] * dyz, ev, gy);
+                gz = fma(w[0][a] * ydz, ev, gz);
+            }
+        }
+    }
+    gx *= sp.inv_h[0]; gy *= sp.inv_h[1]; gz *= sp.inv_h[2];
+    double f = 1.0;
+    if (sp.convention == MSM_AMD_ACC_LITERAL) f = pt.w;      // msmPeriodic.c:1158-1160
+    else if (sp.convention == MSM_AMD_ACC_FORCE) f = -pt.w;
+    const size_t o = 3 * (size_t)order[k];
+    acc[o] += f * gx;
+    acc[o + 1] += f * gy;
+    acc[o + 2] += f * gz;
+}
+
+void launch_interp(hipStream_t st, const double4 *ps_grid, const int *order, int N, const SplineParams &sp,
+                   const double *egrid, int index_shift, double *acc) {
+    const int tb = 256, gb = (N + tb - 1) / tb;
+    if (sp.p == 4) hipLaunchKernelGGL((k_interp<4>), dim3(gb), dim3(tb), 0, st, ps_grid, order, N, sp, egrid, index_shift, acc);
+    else hipLaunchKernelGGL((k_interp<6>), dim3(gb), dim3(tb), 0, st, ps_grid, order, N, sp, egrid, index_shift, acc);
+}
+
+// ---------------------------------------------------------------------------
+// restriction / prolongation, one axis per pass
+// ---------------------------------------------------------------------------
+struct AxisArgs {
+    int Min[3], Mout[3];
+    int axis, h;
+    double J[4];
+};
+
+// out[.., m, ..] = sum_{|j| <= h} J_|j| in[.., (2m + j) mod Min, ..]
+__global__ __launch_bounds__(256) void k_restrict_axis(const double *__restrict__ in, double *__restrict__ out, AxisArgs a) {
+    const size_t n = (size_t)a.Mout[0] * a.Mout[1] * a.Mout[2];
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    int c[3] = {(int)(idx % a.Mout[0]), (int)((idx / a.Mout[0]) % a.Mout[1]), (int)(idx / ((size_t)a.Mout[0] * a.Mout[1]))};
+    const int m = c[a.axis], Ma = a.Min[a.axis];
+    const size_t stride = a.axis == 0 ? 1 : (a.axis == 1 ? (size_t)a.Min[0] : (size_t)a.Min[0] * a.Min[1]);
+    c[a.axis] = 0;
+    const double *base = in + ((size_t)c[2] * a.Min[1] + c[1]) * a.Min[0] + c[0];
+    double s = 0.0;
+    for (int j = -a.h; j <= a.h; j++) s = fma(a.J[j < 0 ? -j : j], base[(size_t)modp(2 * m + j, Ma) * stride], s);
+    out[idx] = s;
+}
+
+// out[.., n, ..] (+)= sum_{|j| <= h, n-j even} J_|j| in[.., ((n-j)/2) mod Min, ..]
+__global__ __launch_bounds__(256) void k_prolong_axis(const double *__restrict__ in, double *__restrict__ out, AxisArgs a,
+                                                      int accumulate) {
+    const size_t n = (size_t)a.Mout[0] * a.Mout[1] * a.Mout[2];
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    int c[3] = {(int)(idx % a.Mout[0]), (int)((idx / a.Mout[0]) % a.Mout[1]), (int)(idx / ((size_t)a.Mout[0] * a.Mout[1]))};
+    const int nn = c[a.axis], Ma = a.Min[a.axis];
+    const size_t stride = a.axis == 0 ? 1 : (a.axis == 1 ? (size_t)a.Min[0] : (size_t)a.Min[0] * a.Min[1]);
+    c[a.axis] = 0;
+    const double *base = in + ((size_t)c[2] * a.Min[1] + c[1]) * a.Min[0] + c[0];
+    double s = 0.0;
+    for (int j = -a.h; j <= a.h; j++) {
+        const int t = nn - j;
+        if (t & 1) continue;
+        s = fma(a.J[j < 0 ? -j : j], base[(size_t)modp(t / 2, Ma) * stride], s);
+    }
+    out[idx] = accumulate ? out[idx] + s : s;
+}
+
+static AxisArgs make_axis(const int Min[3], int axis, int p, const double J[4], bool halve) {
+    AxisArgs a;
+    for (int d = 0; d < 3; d++) { a.Min[d] = Min[d]; a.Mout[d] = Min[d]; }
+    a.Mout[axis] = halve ? Min[axis] / 2 : Min[axis] * 2;
+    a.axis = axis;
+    a.h = p / 2;
+    for (int k = 0; k < 4; k++) a.J[k] = J[k];
+    return a;
+}
+
+void launch_restrict_axis(hipStream_t st, const double *in, double *out, const int Min[3], int axis, int p, const double J[4]) {
+    AxisArgs a = make_axis(Min, axis, p, J, true);
+    const size_t n = (size_t)a.Mout[0] * a.Mout[1] * a.Mout[2];
+    hipLaunchKernelGGL(k_restrict_axis, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, a);
+}
+void launch_prolong_axis(hipStream_t st, const double *in, double *out, const int Min[3], int axis, int p, const double J[4],
+                         int accumulate) {
+    AxisArgs a = make_axis(Min, axis, p, J, false);
+    const size_t n = (size_t)a.Mout[0] * a.Mout[1] * a.Mout[2];
+    hipLaunchKernelGGL(k_prolong_axis, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, a, accumulate);
+}
+
+// ---------------------------------------------------------------------------
+// grid convolution
+// ---------------------------------------------------------------------------
+struct ConvArgs {
+    int M[3], ks[3], kf[3];
+    int z0, nz, accumulate;
+};
+
+__global__ __launch_bounds__(256) void k_conv_direct(const double *__restrict__ q, const double *__restrict__ K,
+                                                     double *__restrict__ e, ConvArgs c) {
+    const int Mx = c.M[0], My = c.M[1], Mz = c.M[2];
+    const size_t nplane = (size_t)Mx * My;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nplane * c.nz) return;
+    const int mx = (int)(idx % Mx), my = (int)((idx / Mx) % My), mz = c.z0 + (int)(idx / nplane);
+    double s = 0.0;
+    for (int sz = 0; sz < c.ks[2]; sz++) {
+        const int nz = modp(mz - (c.kf[2] + sz), Mz);
+        for (int sy = 0; sy < c.ks[1]; sy++) {
+            const int ny = modp(my - (c.kf[1] + sy), My);
+            const double *qrow = q + ((size_t)nz * My + ny) * Mx;
+            const double *krow = K + ((size_t)sz * c.ks[1] + sy) * c.ks[0];
+            for (int sx = 0; sx < c.ks[0]; sx++) s = fma(krow[sx], qrow[modp(mx - (c.kf[0] + sx), Mx)], s);
+        }
+    }
+    const size_t o = ((size_t)mz * My + my) * Mx + mx;
+    e[o] = c.accumulate ? e[o] + s : s;
+}
+
+void launch_conv_direct(hipStream_t st, const double *q, const double *K, const int M[3], const int ksize[3],
+                        const int kfirst[3], double *e, int z0, int nz, int accumulate) {
+    ConvArgs c;
+    for (int d = 0; d < 3; d++) { c.M[d] = M[d]; c.ks[d] = ksize[d]; c.kf[d] = kfirst[d]; }
+    c.z0 = z0; c.nz = nz; c.accumulate = accumulate;
+    const size_t n = (size_t)M[0] * M[1] * nz;
+    hipLaunchKernelGGL(k_conv_direct, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, q, K, e, c);
+}
+
+// LDS-tiled convolution.  A workgroup owns TX x TY x TZ outputs and stages the
+// (TX+sx-1)(TY+sy-1)(TZ+SZ-1) inputs they touch in LDS once (periodic wrap applied while staging).
+// A thread owns R consecutive outputs along z at one (x,y): for each (sx,sy) it reads a window of R+SZ-1
+// inputs (lanes are consecutive in x, so every LDS read is a conflict-free row segment) and feeds R*SZ FMAs.
+// The SZ coefficients of that (sx,sy) are contiguous in the transposed stencil Kt[sy][sx][sz] and uniform
+// across the wave, so they arrive through scalar loads and cost no LDS bandwidth.
+template <int SZ, int R, int TX, int TY, int TZ>
+__global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_tiled(const double *__restrict__ q, const double *__restrict__ Kt,
+                                                                double *__restrict__ e, ConvArgs c, int ntx, int nty) {
+    extern __shared__ double lds[];
+    const int Mx = c.M[0], My = c.M[1], Mz = c.M[2];
+    const int sxn = c.ks[0], syn = c.ks[1];
+    const int LX = TX + sxn - 1, LY = TY + syn - 1, LZ = TZ + SZ - 1;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = bid % ntx, by = (bid / ntx) % nty, bz = bid / (ntx * nty);
+    const int X0 = bx * TX, Y0 = by * TY, Z0 = c.z0 + bz * TZ;
+    const int ox = X0 - (c.kf[0] + sxn - 1), oy = Y0 - (c.kf[1] + syn - 1), oz = Z0 - (c.kf[2] + SZ - 1);
+    const int nthreads = TX * TY * (TZ / R);
+    for (int t = threadIdx.x; t < LX * LY * LZ; t += nthreads) {
+        const int lx = t % LX, ly = (t / LX) % LY, lz = t / (LX * LY);
+        lds[t] = q[((size_t)modp(oz + lz, Mz) * My + modp(oy + ly, My)) * Mx + modp(ox + lx, Mx)];
+    }
+    __syncthreads();
+    const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) % TY, tg = threadIdx.x / (TX * TY);
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.0;
+    for (int sy = 0; sy < syn; sy++) {
+        for (int sx = 0; sx < sxn; sx++) {
+            const double *col = lds + ((size_t)(tg * R) * LY + (ty + syn - 1 - sy)) * LX + (tx + sxn - 1 - sx);
+            double v[R + SZ - 1];
+#pragma unroll
+            for (int w = 0; w < R + SZ - 1; w++) v[w] = col[(size_t)w * LY * LX];
+            const double *kk = Kt + ((size_t)sy * sxn + sx) * SZ;
+#pragma unroll
+            for (int sz = 0; sz < SZ; sz++) {
+                const double kv = kk[sz];
+#pragma unroll
+                for (int r = 0; r < R; r++) acc[r] = fma(kv, v[r + SZ - 1 - sz], acc[r]);
+            }
+        }
+    }
+    const int mx = X0 + tx, my = Y0 + ty;
+    if (mx < Mx && my < My) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int mz = Z0 + tg * R + r;
+            if (mz < c.z0 + c.nz && mz < Mz) e[((size_t)mz * My + my) * Mx + mx] = acc[r];
+        }
+    }
+}
+
+template <int SZ, int R, int TX, int TY, int TZ>
+static bool conv_tiled_launch(hipStream_t st, const double *q, const double *Kt, double *e, const ConvArgs &c) {
+    const int LX = TX + c.ks[0] - 1, LY = TY + c.ks[1] - 1, LZ = TZ + SZ - 1;
+    const size_t bytes = sizeof(double) * (size_t)LX * LY * LZ;
+    if (bytes > 160 * 1024) return false;
+    const int ntx = (c.M[0] + TX - 1) / TX, nty = (c.M[1] + TY - 1) / TY, ntz = (c.nz + TZ - 1) / TZ;
+    auto kern = k_conv_tiled<SZ, R, TX, TY, TZ>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(ntx * nty * ntz), dim3(TX * TY * (TZ / R)), bytes, st, q, Kt, e, c, ntx, nty);
+    return true;
+}
+
+bool launch_conv_tiled(hipStream_t st, const double *q, const double *Kt, const int M[3], const int ksize[3],
+                       const int kfirst[3], double *e, int z0, int nz) {
+    ConvArgs c;
+    for (int d = 0; d < 3; d++) { c.M[d] = M[d]; c.ks[d] = ksize[d]; c.kf[d] = kfirst[d]; }
+    c.z0 = z0; c.nz = nz; c.accumulate = 0;
+    switch (ksize[2]) {
+#define CASE_SZ(S)                                                                             \
+    case S:                                                                                    \
+        if (conv_tiled_launch<S, 4, 16, 8, 8>(st, q, Kt, e, c)) return true;                   \
+        return conv_tiled_launch<S, 4, 16, 4, 8>(st, q, Kt, e, c);
+        CASE_SZ(7)
+        CASE_SZ(9)
+        CASE_SZ(11)
+        CASE_SZ(13)
+        CASE_SZ(15)
+        CASE_SZ(17)
+        CASE_SZ(19)
+#undef CASE_SZ
+    default:
+        return false;
+    }
+}
+
+// The reference's grid-to-grid mapping as written (msmPeriodic.c:874-918, 962-998): dense double loop over
+// all node pairs, stencil offset (mx - nz, my - ny, mz - nz) wrapped into [first, first+size-1] by the
+// stencil size.  Used in literal mode only.
+__global__ __launch_bounds__(64) void k_conv_literal(const double *__restrict__ q, const double *__restrict__ K,
+                                                     double *__restrict__ e, ConvArgs c) {
+    const int Mx = c.M[0], My = c.M[1], Mz = c.M[2];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Mx * My * Mz) return;
+    const int mx = idx % Mx, my = (idx / Mx) % My, mz = idx / (Mx * My);
+    double s = 0.0;
+    for (int nz = 0; nz < Mz; nz++) {
+        int ox = mx - nz, oz = mz - nz;
+        const int lox = c.kf[0], hix = c.kf[0] + c.ks[0] - 1, loz = c.kf[2], hiz = c.kf[2] + c.ks[2] - 1;
+        while (ox < lox) ox += c.ks[0];
+        while (ox > hix) ox -= c.ks[0];
+        while (oz < loz) oz += c.ks[2];
+        while (oz > hiz) oz -= c.ks[2];
+        for (int ny = 0; ny < My; ny++) {
+            int oy = my - ny;
+            const int loy = c.kf[1], hiy = c.kf[1] + c.ks[1] - 1;
+            while (oy < loy) oy += c.ks[1];
+            while (oy > hiy) oy -= c.ks[1];
+            const double kv = K[((size_t)(oz - loz) * c.ks[1] + (oy - loy)) * c.ks[0] + (ox - lox)];
+            const double *qrow = q + ((size_t)nz * My + ny) * Mx;
+            for (int nx = 0; nx < Mx; nx++) s = fma(kv, qrow[nx], s);
+        }
+    }
+    e[idx] = s;
+}
+
+void launch_conv_literal(hipStream_t st, const double *q, const double *K, const int M[3], const int ksize[3],
+                         const int kfirst[3], double *e) {
+    ConvArgs c;
+    for (int d = 0; d < 3; d++) { c.M[d] = M[d]; c.ks[d] = ksize[d]; c.kf[d] = kfirst[d]; }
+    c.z0 = 0; c.nz = M[2]; c.accumulate = 0;
+    const int n = M[0] * M[1] * M[2];
+    hipLaunchKernelGGL(k_conv_literal, dim3((n + 63) / 64), dim3(64), 0, st, q, K, e, c);
+}
+
+__global__ void k_axpy(double *__restrict__ y, const double *__restrict__ x, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += x[i];
+}
+void launch_axpy(hipStream_t st, double *y, const double *x, size_t n) {
+    hipLaunchKernelGGL(k_axpy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, x, n);
+}
+
+// ---------------------------------------------------------------------------
+// reductions (fixed summation trees: results do not depend on scheduling)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dot_partials(const double *__restrict__ a, const double *__restrict__ b, size_t n,
+                                                      double *__restrict__ parts) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s = fma(a[i], b[i], s);
+    const double t = block_sum<256>(s, red);
+    if (threadIdx.x == 0) parts[blockIdx.x] = t;
+}
+void launch_dot_partials(hipStream_t st, const double *a, const double *b, size_t n, double *parts, int nparts) {
+    hipLaunchKernelGGL(k_dot_partials, dim3(nparts), dim3(256), 0, st, a, b, n, parts);
+}
+
+__global__ __launch_bounds__(256) void k_charge_partials(const double *__restrict__ q, size_t n, double *__restrict__ parts,
+                                                         int nparts) {
+    __shared__ double red[256];
+    double s = 0.0, s2 = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double v = q[i];
+        s += v;
+        s2 = fma(v, v, s2);
+    }
+    const double t = block_sum<256>(s, red);
+    __syncthreads();
+    const double t2 = block_sum<256>(s2, red);
+    if (threadIdx.x == 0) {
+        parts[blockIdx.x] = t;
+        parts[nparts + blockIdx.x] = t2;
+    }
+}
+void launch_charge_partials(hipStream_t st, const double *q, size_t n, double *parts, int nparts) {
+    hipLaunchKernelGGL(k_charge_partials, dim3(nparts), dim3(256), 0, st, q, n, parts, nparts);
+}
+
+__device__ double sum_array(const double *__restrict__ p, int n, double *red) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += p[i];
+    const double t = block_sum<256>(s, red);
+    __syncthreads();
+    return t;
+}
+
+// (A)..(F) and the total (msmPeriodic.c:1305-1359; msmSimple.c:1968-1969)
+__global__ __launch_bounds__(256) void k_finalize_energies(EnergyInputs in, double *__restrict__ out) {
+    __shared__ double red[256];
+    const double ua = sum_array(in.pair_parts, in.n_pair, red);
+    const double qe = sum_array(in.grid_parts, in.n_grid, red);
+    const double qf = sum_array(in.four_parts, in.n_four, red);
+    const double qs = sum_array(in.charge_parts, in.n_charge, red);
+    const double qs2 = sum_array(in.charge_parts + in.n_charge, in.n_charge, red);
+    if (threadIdx.x == 0) {
+        double ulr, ulf;
+        if (in.literal) { // msmPeriodic.c:1002 (minus sign), :1334-1338 (edir only)
+            ulr = 0.5 * qe;
+            ulf = -0.5 * qf;
+        } else {
+            ulf = 0.5 * qf;
+            ulr = 0.5 * qe - ulf;
+        }
+        out[MSM_AMD_U_SHORT_REAL] = ua;
+        out[MSM_AMD_U_SHORT_SELF] = 0.5 * qs2 * in.self_image_sum;
+        out[MSM_AMD_U_SHORT_CSR] = -0.5 * qs * qs * in.csr;
+        out[MSM_AMD_U_LONG_REAL] = ulr;
+        out[MSM_AMD_U_LONG_FOUR] = ulf;
+        out[MSM_AMD_U_LONG_SELF] = -0.5 * qs2 * in.gamma0_over_a;
+        out[MSM_AMD_U_TOTAL] = (ulf + ulr + out[MSM_AMD_U_LONG_SELF]) +
+                               (ua + out[MSM_AMD_U_SHORT_SELF] + out[MSM_AMD_U_SHORT_CSR]);
+    }
+}
+void launch_finalize_energies(hipStream_t st, const EnergyInputs &in, double *out7) {
+    hipLaunchKernelGGL(k_finalize_energies, dim3(1), dim3(256), 0, st, in, out7);
+}
+
+} // namespace msm

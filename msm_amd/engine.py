@@ -1,0 +1,243 @@
+"""Host-side mirror of the reference's operator interface on top of the C ABI.
+
+`msmperiodic(...)` mirrors msmperiodic() of msm/msmLibrary.h:188 (same argument
+meaning, same side effect on `r` in literal mode) and `Engine` is the
+device-resident form: a plan built once, then energy + acceleration
+evaluations on tensors that stay in HBM.  PyTorch is used for device memory
+and streams only; all arithmetic happens in libmsm_amd.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import PlanDesc, MsmStats, check, load
+
+_dp = C.POINTER(C.c_double)
+
+
+def plan_auto(N, A, p=4, mu=10, abar=4.0, L=0):
+    """The reference's parameter choices (msmPeriodic.c:147-263) for L grid levels (L=0: pick)."""
+    d = PlanDesc()
+    check(load().msm_amd_plan_auto(int(N), float(A[0]), float(A[1]), float(A[2]), int(p), int(mu), float(abar), int(L),
+                                   C.byref(d)), "msm_amd_plan_auto")
+    return d
+
+
+def plan_explicit(N, A, M, p, mu, L, a, beta, kmax, acc_convention=capi.ACC_GRADIENT):
+    d = PlanDesc()
+    d.N, d.p, d.mu, d.L, d.kmax, d.acc_convention = int(N), int(p), int(mu), int(L), int(kmax), int(acc_convention)
+    for k in range(3):
+        d.M[k] = int(M[k])
+        d.A[k] = float(A[k])
+    d.zplane0, d.nzplanes, d.n_owned = 0, int(M[2]), 0
+    d.a, d.beta = float(a), float(beta)
+    return d
+
+
+class HostPlan:
+    """Position-independent part of a plan (omega', stencils); needs no GPU."""
+
+    def __init__(self, desc, literal=False):
+        self.desc = desc
+        self._h = C.c_void_p()
+        check(load().msm_amd_hostplan_create(C.byref(desc), 1 if literal else 0, C.byref(self._h)),
+              "msm_amd_hostplan_create")
+
+    def close(self):
+        if self._h:
+            load().msm_amd_hostplan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stencil(self, level):
+        """(values[z][y][x], first[3]) of grid level `level`; level == L is the Fourier top stencil."""
+        size = (C.c_int * 3)()
+        first = (C.c_int * 3)()
+        check(load().msm_amd_hostplan_stencil_info(self._h, level, size, first), "stencil_info")
+        out = np.zeros(size[0] * size[1] * size[2])
+        check(load().msm_amd_hostplan_copy_stencil(self._h, level, out.ctypes.data_as(_dp)), "copy_stencil")
+        return out.reshape(size[2], size[1], size[0]), list(first)
+
+    def wprime(self):
+        n = C.c_int(0)
+        check(load().msm_amd_hostplan_copy_wprime(self._h, None, C.byref(n)), "copy_wprime")
+        w = np.zeros(n.value)
+        check(load().msm_amd_hostplan_copy_wprime(self._h, w.ctypes.data_as(_dp), C.byref(n)), "copy_wprime")
+        return w
+
+    def scalars(self):
+        s = np.zeros(8)
+        check(load().msm_amd_hostplan_scalars(self._h, s.ctypes.data_as(_dp)), "hostplan_scalars")
+        return {"csr": s[0], "self_image_sum": s[1], "gamma0": s[2], "chisum": s[3], "J": s[4:8].copy()}
+
+
+class Engine:
+    """A plan plus its device buffers on one GPU; evaluations reuse them (no allocation per call)."""
+
+    def __init__(self, desc, device=0, literal=False, stream=None):
+        import torch  # device memory and streams only
+        if not torch.cuda.is_available():
+            raise capi.MsmAmdError("msm_amd needs a HIP device; none is visible and there is no CPU path")
+        self.torch = torch
+        self.desc = desc
+        self.device = device
+        self.literal = literal
+        self._h = C.c_void_p()
+        sp = C.c_void_p(stream) if stream else None
+        fn = load().msm_amd_create_literal if literal else load().msm_amd_create
+        check(fn(C.byref(desc), device, sp, C.byref(self._h)), "msm_amd_create")
+        self.N = desc.N
+        self.L = desc.L
+
+    def close(self):
+        if self._h:
+            load().msm_amd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- whole evaluation ----
+    def _dev(self, x, n):
+        t = self.torch
+        if not isinstance(x, t.Tensor):
+            x = t.as_tensor(np.ascontiguousarray(x, dtype=np.float64), device="cuda:%d" % self.device)
+        assert x.dtype == t.float64 and x.is_cuda and x.is_contiguous() and x.numel() == n
+        return x
+
+    def eval(self, r, q, acc=None, want_energies=True):
+        """r (N,3) and q (N,) float64 CUDA tensors (or arrays, then uploaded).  Returns (energies[7] or None, acc)."""
+        t = self.torch
+        r = self._dev(r, 3 * self.N)
+        q = self._dev(q, self.N)
+        if acc is None:
+            acc = t.empty((self.N, 3), dtype=t.float64, device=r.device)
+        en = np.zeros(capi.U_COUNT) if want_energies else None
+        check(load().msm_amd_eval(self._h, r.data_ptr(), q.data_ptr(), acc.data_ptr(),
+                                  en.ctypes.data_as(_dp) if want_energies else None), "msm_amd_eval")
+        return en, acc
+
+    def eval_host(self, r, q):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        acc = np.zeros((self.N, 3))
+        en = np.zeros(capi.U_COUNT)
+        check(load().msm_amd_eval_host(self._h, r.ctypes.data_as(_dp), q.ctypes.data_as(_dp), acc.ctypes.data_as(_dp),
+                                       en.ctypes.data_as(_dp)), "msm_amd_eval_host")
+        return en, acc
+
+    # ---- stages ----
+    def stage_bin(self, r, q):
+        self._r = self._dev(r, 3 * self.N)
+        self._q = self._dev(q, self.N)
+        check(load().msm_amd_stage_bin(self._h, self._r.data_ptr(), self._q.data_ptr()), "stage_bin")
+
+    def stage_pairs(self, acc):
+        check(load().msm_amd_stage_pairs(self._h, acc.data_ptr()), "stage_pairs")
+
+    def stage_anterpolate(self):
+        check(load().msm_amd_stage_anterpolate(self._h), "stage_anterpolate")
+
+    def stage_grid(self):
+        check(load().msm_amd_stage_grid(self._h), "stage_grid")
+
+    def stage_interpolate(self, acc):
+        check(load().msm_amd_stage_interpolate(self._h, acc.data_ptr()), "stage_interpolate")
+
+    def stage_energies(self):
+        en = np.zeros(capi.U_COUNT)
+        check(load().msm_amd_stage_energies(self._h, en.ctypes.data_as(_dp)), "stage_energies")
+        return en
+
+    # ---- state ----
+    def grid_dims(self, level):
+        d = (C.c_int * 3)()
+        check(load().msm_amd_grid_dims(self._h, level, d), "grid_dims")
+        return list(d)
+
+    def grid(self, which, level=0):
+        d = self.grid_dims(self.L - 1 if which == capi.GRID_EFOUR else level)
+        out = np.zeros(d[0] * d[1] * d[2])
+        check(load().msm_amd_copy_grid(self._h, which, level, out.ctypes.data_as(_dp)), "copy_grid")
+        return out.reshape(d[2], d[1], d[0])
+
+    def set_grid(self, which, level, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        check(load().msm_amd_set_grid(self._h, which, level, v.ctypes.data_as(_dp)), "set_grid")
+
+    def grid_tensor(self, which, level=0):
+        """Zero-copy torch view of an internal grid (used by the slab all-gather)."""
+        import ctypes
+        t = self.torch
+        d = self.grid_dims(self.L - 1 if which == capi.GRID_EFOUR else level)
+        ptr = load().msm_amd_grid_device_ptr(self._h, which, level)
+        n = d[0] * d[1] * d[2]
+        # wrap the raw pointer through the CUDA array interface
+        class _Wrap:
+            pass
+        w = _Wrap()
+        w.__cuda_array_interface__ = {"shape": (d[2], d[1], d[0]), "typestr": "<f8", "data": (int(ptr), False),
+                                      "version": 2}
+        return t.as_tensor(w, device="cuda:%d" % self.device)
+
+    def stencil(self, level):
+        size = (C.c_int * 3)()
+        first = (C.c_int * 3)()
+        check(load().msm_amd_stencil_info(self._h, level, size, first), "stencil_info")
+        out = np.zeros(size[0] * size[1] * size[2])
+        check(load().msm_amd_copy_stencil(self._h, level, out.ctypes.data_as(_dp)), "copy_stencil")
+        return out.reshape(size[2], size[1], size[0]), list(first)
+
+    def op_restrict(self, level, fine, coarse):
+        check(load().msm_amd_op_restrict(self._h, level, fine.data_ptr(), coarse.data_ptr()), "op_restrict")
+
+    def op_prolong_add(self, level, coarse, fine):
+        check(load().msm_amd_op_prolong_add(self._h, level, coarse.data_ptr(), fine.data_ptr()), "op_prolong_add")
+
+    def op_convolve(self, level, q, e):
+        check(load().msm_amd_op_convolve(self._h, level, q.data_ptr(), e.data_ptr()), "op_convolve")
+
+    def set_profiling(self, on=True):
+        load().msm_amd_set_profiling(self._h, 1 if on else 0)
+
+    def set_option(self, key, value):
+        check(load().msm_amd_set_option(self._h, key.encode(), int(value)), "set_option")
+
+    def last_timings(self):
+        ms = np.zeros(10)
+        check(load().msm_amd_last_timings(self._h, ms.ctypes.data_as(_dp)), "last_timings")
+        names = ("bin", "pairs", "anterpolation", "restriction", "convolution", "top", "prolongation", "interpolation",
+                 "reductions", "total")
+        return dict(zip(names, ms))
+
+
+def msmperiodic(r, q, p, abar, mu, A, mode=None, quiet=True):
+    """msmperiodic() of msm/msmLibrary.h:188 through the C ABI.
+
+    r (N,3) float64 array (shifted in place by +0.5 in literal mode, as the reference does), q (N,).
+    Returns (stats: MsmStats, uappr: float, fappr: (N,3) array)."""
+    lib = load()
+    r = np.ascontiguousarray(r, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    n = q.shape[0]
+    f = np.zeros((n, 3))
+    u = C.c_double(0.0)
+    old = lib.msm_amd_get_mode()
+    if mode is not None:
+        lib.msm_amd_set_mode(mode)
+    lib.msm_amd_set_quiet(1 if quiet else 0)
+    try:
+        st = lib.msmperiodic(n, r.ctypes.data_as(_dp), q.ctypes.data_as(_dp), int(p), float(abar), int(mu), C.byref(u),
+                             f.ctypes.data_as(_dp), float(A[0]), float(A[1]), float(A[2]))
+    finally:
+        lib.msm_amd_set_mode(old)
+    return st, u.value, f, r

@@ -34,6 +34,11 @@ struct or_spec_plan {
     double *qg[OR_MAXL], *eg[OR_MAXL], *efour;
 };
 
+/* 0: sum every periodic image that can contribute; R > 0: images -R..R only, as the reference's
+ * hard-wired -5..5 (msmPeriodic.c:536-538) */
+static int g_image_range = 0;
+void or_spec_set_image_range(int R) { g_image_range = R; }
+
 static double now_s(void) {
 #ifdef _OPENMP
     return omp_get_wtime();
@@ -96,6 +101,7 @@ static void build_level_stencil(or_spec_plan *pl, int l) {
     for (d = 0; d < 3; d++) {
         int jmax = (abs(lo[d]) > abs(hi[d]) ? abs(lo[d]) : abs(hi[d])) + W;
         R[d] = (int)ceil((jmax * pl->hl[l][d] + rcut) / P->A[d]);
+        if (g_image_range > 0) R[d] = g_image_range;
     }
     G = (double *)malloc(sizeof(double) * (size_t)ext[0] * ext[1] * ext[2]);
 #pragma omp parallel for collapse(2) private(nx, px, py, pz)

@@ -96,6 +96,8 @@ def lib():
                                                                     C.POINTER(SpecParams)]
     L.or_spec_plan_create.restype = C.c_void_p
     L.or_spec_plan_create.argtypes = [C.POINTER(SpecParams)]
+    L.or_spec_set_image_range.restype = None
+    L.or_spec_set_image_range.argtypes = [C.c_int]
     L.or_spec_plan_destroy.restype = None
     L.or_spec_plan_destroy.argtypes = [C.c_void_p]
     L.or_spec_stencil.restype = _dp
