@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""MSM energy+force evaluations per second at N = 1M periodic on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" is one whole evaluation of the hot path on particles already resident in HBM: binning ->
+short-range pair sum -> anterpolation -> restrictions -> per-level grid convolutions -> Fourier top level ->
+prolongations -> interpolation -> energy reductions (and, for N > 1 ranks, the level-0 charge all-gather and
+the energy all-reduce).  Position-independent setup (beta, kmax, omega', stencils, allocation, communicator)
+is outside the timed region.  Positions are perturbed between steps so nothing can be cached.
+
+Workload: BASELINE.json configs[2] (the configuration the metric is quoted on): 1,000,000 charge-neutral
+particles in a periodic unit cube, quintic B-spline (p = 6) unless --order 4, abar = 4, mu = 10, four grid
+levels 96 -> 48 -> 24 -> 12 plus the Fourier top level.  N > 1 keeps the total work fixed (strong scaling):
+the same million particles are split into z slabs.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the pair sum): algorithmic flops
+(ordered in-cutoff pairs x 34 flop at p=4 / 42 at p=6) over the kernel's mean duration measured with HIP
+events on the stream the kernel runs on.  `cpu_baseline` is the CPU oracle (a port of the same mathematics,
+oracle/msm_spec.c) timed on this box's host cores on one evaluation of the same system.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+FP64_PEAK_TFLOPS = 78.6   # gfx950 vector FP64: 256 CU x 128 flop/clk x 2.4 GHz
+FLOP_PER_PAIR = {4: 34, 6: 42}
+
+
+def make_system(N, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    r = rng.random((N, 3))
+    q = np.where(np.arange(N) % 2 == 0, 1.0, -1.0)
+    return r, q
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--particles", type=int, default=1000000)
+    ap.add_argument("--order", type=int, default=6, choices=(4, 6))
+    ap.add_argument("--levels", type=int, default=0, help="grid levels (0: the reference's formula, capped)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pair-variant", type=int, default=-1)
+    args = ap.parse_args()
+
+    import torch
+    import msm_amd
+    from msm_amd import capi
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path in msm_amd)")
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+
+    N, p, mu, abar = args.particles, args.order, 10, 4.0
+    A = (1.0, 1.0, 1.0)
+    r_all, q_all = make_system(N, 20261111 + 2)
+    desc = msm_amd.plan_auto(N, A, p, mu, abar, args.levels)
+
+    if world == 1:
+        eng = msm_amd.Engine(desc, device=local_rank)
+        if args.pair_variant >= 0:
+            eng.set_option("pair_variant", args.pair_variant)
+        stepper = SingleGpu(torch, eng, r_all, q_all, dev)
+    else:
+        from msm_amd.slab import SlabRank
+        stepper = SlabRank(torch, dist, msm_amd, desc, r_all, q_all, rank, world, local_rank)
+        eng = stepper.eng
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        stepper.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stepper.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    energies = stepper.last_energies
+
+    # per-kernel durations with HIP events on the engine's stream (separate, untimed pass)
+    eng.set_profiling(True)
+    acc_ms = {}
+    nprof = max(3, min(10, args.steps))
+    for _ in range(nprof):
+        stepper.step()
+        for k, v in eng.last_timings().items():
+            acc_ms[k] = acc_ms.get(k, 0.0) + v / nprof
+    eng.set_profiling(False)
+
+    pairs = N * (4.0 * math.pi / 3.0) * abar ** 3 / world   # ordered in-cutoff pairs handled by one rank's launch
+    flops = pairs * FLOP_PER_PAIR[p]
+    pair_s = acc_ms["pairs"] * 1e-3
+    achieved = flops / pair_s / 1e12 if pair_s > 0 else 0.0
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(desc, r_all, q_all)
+
+    if rank == 0:
+        out = {
+            "metric": "MSM energy+force evals/sec at N=1M periodic",
+            "value": args.steps / elapsed,
+            "unit": "evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "periodic unit cube, %d charge-neutral random particles, B-spline order p=%d, "
+                                   "abar=4, mu=10, grid %s, %d levels + Fourier top (kmax=%d)"
+                                   % (N, p, "x".join(str(m) for m in desc.M), desc.L, desc.kmax),
+                       "particles": N, "order": p, "levels": desc.L, "grid": list(desc.M),
+                       "parallelism": "single GPU" if world == 1 else "z-slabs x%d, level-0 charge all-gather" % world},
+            "roofline": {"kernel": "k_pair_cells (short-range pair sum)", "bound": "mfma", "achieved": achieved,
+                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+                         "traffic": None,
+                         "note": "FP64 vector FMA bound (the FP64 MFMA peak is the same 78.6 TF); algorithmic flops = "
+                                 "N*(4pi/3)*abar^3 ordered pairs x %d flop" % FLOP_PER_PAIR[p]},
+            "kernel_ms": acc_ms,
+            "energies": dict(zip(capi.U_NAMES, [float(x) for x in energies])) if energies is not None else None,
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+class SingleGpu:
+    def __init__(self, torch, eng, r, q, dev):
+        self.torch = torch
+        self.eng = eng
+        self.r = torch.as_tensor(r, device=dev)
+        self.q = torch.as_tensor(q, device=dev)
+        self.acc = torch.empty_like(self.r)
+        g = torch.Generator(device=dev)
+        g.manual_seed(7)
+        # small pre-generated displacement, re-applied with alternating sign: positions change every step
+        self.delta = (torch.rand(self.r.shape, generator=g, dtype=torch.float64, device=dev) - 0.5) * 1e-4
+        self.sign = 1.0
+        self.last_energies = None
+
+    def step(self):
+        self.r.add_(self.delta, alpha=self.sign)
+        self.sign = -self.sign
+        self.last_energies, _ = self.eng.eval(self.r, self.q, self.acc)
+
+
+def cpu_baseline(desc, r, q):
+    """The CPU oracle (oracle/msm_spec.c: the same mathematics as the GPU path, C + OpenMP) on this box."""
+    import oracle_lib as O
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    sp = O.SpecPlan.explicit(desc.N, list(desc.A), list(desc.M), desc.p, desc.mu, desc.L, desc.a, desc.beta, desc.kmax,
+                             nthreads=cores)
+    t0 = time.perf_counter()
+    out = sp.eval(r, q)
+    dt = time.perf_counter() - t0
+    names = ("pairs", "anterpolation", "restriction", "convolution", "top", "prolongation", "interpolation", "total")
+    return {"value": 1.0 / dt, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": "1 evaluation of the same %d-particle system (all stages)" % desc.N,
+            "stage_seconds": dict(zip(names, [float(x) for x in out["seconds"]])),
+            "utotal": float(out["energies"][6])}
+
+
+if __name__ == "__main__":
+    main()

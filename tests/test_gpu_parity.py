@@ -1,0 +1,369 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and with the reference's golden outputs.
+
+Tolerances (FP64 everywhere): energies 1e-12 relative to the largest energy component of the system;
+accelerations 1e-12 relative RMS (sqrt(sum|f-f_ref|^2 / sum|f_ref|^2)), with a floor of one pair term for
+systems whose accelerations cancel by symmetry; grids 1e-12 relative to the grid's largest entry.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+
+
+def rel_rms(a, b, floor=0.0):
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    den = max(np.sqrt((b ** 2).sum()), floor * np.sqrt(b.size))
+    return np.sqrt(((a - b) ** 2).sum()) / max(den, 1e-300)
+
+
+def grid_err(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    return t
+
+
+@pytest.fixture(scope="module")
+def msm():
+    import msm_amd
+    msm_amd.load()
+    return msm_amd
+
+
+def spec_for(desc, nthreads=8):
+    return O.SpecPlan.explicit(desc.N, list(desc.A), list(desc.M), desc.p, desc.mu, desc.L, desc.a, desc.beta, desc.kmax,
+                               nthreads=nthreads)
+
+
+def system(name):
+    fx = O.golden("msmPeriodic_%s.json" % name)
+    s = fx["system"]
+    return fx, np.array(s["r"]).reshape(-1, 3), np.array(s["q"]), s["L"]
+
+
+CASES = [  # (N, box, p, mu, L)
+    (3000, (1.0, 1.0, 1.0), 4, 10, 1),     # cells path, compact stencil? M=16: full range
+    (3000, (1.0, 1.0, 1.0), 4, 10, 2),
+    (3000, (1.0, 1.0, 1.0), 6, 6, 2),
+    (20000, (1.0, 1.0, 1.0), 4, 10, 2),    # M=32: compact 15^3 stencil at level 0 -> tiled kernel
+    (20000, (1.3, 0.9, 1.1), 4, 10, 2),    # non-cubic cell
+    (300, (1.0, 1.0, 1.0), 4, 10, 1),      # small box: all-images pair kernel
+    (64, (2.0, 2.0, 2.0), 6, 4, 1),
+]
+
+
+@pytest.mark.parametrize("N,A,p,mu,L", CASES)
+def test_stagewise_parity(msm, torch, N, A, p, mu, L):
+    r, q = O.neutral_system(N, A, seed=100 + N + p + L)
+    r[0] = [0.0, 0.0, 0.0]                       # on the cell corner
+    r[1] = [A[0] * 1.25, -0.3 * A[1], A[2] * 2]  # outside the primary cell: must be wrapped
+    desc = msm.plan_auto(N, A, p, mu, 4.0, L)
+    sp = spec_for(desc)
+    eng = msm.Engine(desc)
+    dev = "cuda:0"
+    rd = torch.as_tensor(r, device=dev)
+    qd = torch.as_tensor(q, device=dev)
+
+    # stencils (host side, but part of the product)
+    for l in range(L):
+        K, first = eng.stencil(l)
+        Ko, fo = sp.stencil(l)
+        assert first == fo and K.shape == Ko.shape
+        assert grid_err(K, Ko) < (1e-11 if p == 6 else 1e-12)
+    assert grid_err(eng.stencil(L)[0], sp.stencil_top()) < 1e-12
+
+    # short range
+    eng.stage_bin(rd, qd)
+    acc_s = torch.zeros((N, 3), dtype=torch.float64, device=dev)
+    eng.stage_pairs(acc_s)
+    aw, au, ureal = sp.pairs(r, q)
+    assert rel_rms(acc_s.cpu().numpy(), aw) < TOL
+
+    # anterpolation
+    eng.stage_anterpolate()
+    g0 = eng.grid(msm.capi.GRID_Q, 0)
+    g0o = sp.anterpolate(r, q)
+    assert grid_err(g0, g0o) < TOL
+    assert abs(g0.sum() - q.sum()) < 1e-9 * max(np.abs(q).sum(), 1)
+
+    # single grid operators on the oracle's grids
+    grids_q = [g0o]
+    for l in range(L - 1):
+        fine = torch.as_tensor(grids_q[l], device=dev)
+        d = eng.grid_dims(l + 1)
+        coarse = torch.zeros((d[2], d[1], d[0]), dtype=torch.float64, device=dev)
+        eng.op_restrict(l, fine, coarse)
+        co = sp.restrict(l, grids_q[l])
+        assert grid_err(coarse.cpu().numpy(), co) < TOL
+        grids_q.append(co)
+    for l in range(L):
+        qg = torch.as_tensor(grids_q[l], device=dev)
+        e = torch.zeros_like(qg)
+        eo = sp.convolve(l, grids_q[l])
+        for tiled in (0, 1):
+            eng.set_option("conv_tiled", tiled)
+            e.zero_()
+            eng.op_convolve(l, qg, e)
+            assert grid_err(e.cpu().numpy(), eo) < TOL, ("level", l, "tiled", tiled)
+    qg = torch.as_tensor(grids_q[L - 1], device=dev)
+    e = torch.zeros_like(qg)
+    eng.op_convolve(L, qg, e)
+    assert grid_err(e.cpu().numpy(), sp.convolve_top(grids_q[L - 1])) < TOL
+    if L > 1:
+        rng = np.random.default_rng(3)
+        d1, d0 = eng.grid_dims(1), eng.grid_dims(0)
+        c = rng.standard_normal((d1[2], d1[1], d1[0]))
+        f = rng.standard_normal((d0[2], d0[1], d0[0]))
+        fd = torch.as_tensor(f, device=dev)
+        eng.op_prolong_add(0, torch.as_tensor(c, device=dev), fd)
+        assert grid_err(fd.cpu().numpy(), sp.prolong_add(0, c, f)) < TOL
+
+    # whole grid stage, interpolation, energies
+    eng.stage_grid()
+    ref = sp.eval(r, q)
+    for l in range(L):
+        assert grid_err(eng.grid(msm.capi.GRID_E, l), sp.grid("e", l)) < TOL
+    acc_l = torch.zeros((N, 3), dtype=torch.float64, device=dev)
+    eng.stage_interpolate(acc_l)
+    assert rel_rms(acc_l.cpu().numpy(), ref["along"]) < TOL
+    en = eng.stage_energies()
+    scale = np.abs(ref["energies"][:6]).max()
+    assert np.abs(en - ref["energies"]).max() < TOL * scale, (en, ref["energies"])
+
+    # and the one-call form
+    en2, acc = eng.eval(rd, qd)
+    assert np.abs(en2 - ref["energies"]).max() < TOL * scale
+    assert rel_rms(acc.cpu().numpy(), ref["acc"]) < TOL
+    en3, acc3 = eng.eval_host(r, q)
+    assert np.array_equal(en3, en2) and np.array_equal(acc3, acc.cpu().numpy())  # deterministic
+    eng.close()
+    sp.close()
+
+
+def test_pair_kernel_variants_agree(msm, torch):
+    N, A = 30000, (1.0, 1.0, 1.0)
+    r, q = O.neutral_system(N, A, seed=77)
+    desc = msm.plan_auto(N, A, 4, 10, 4.0, 2)
+    eng = msm.Engine(desc)
+    rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
+    out = []
+    for v in (1, 2):
+        eng.set_option("pair_variant", v)
+        en, acc = eng.eval(rd, qd)
+        out.append((en.copy(), acc.cpu().numpy().copy()))
+    assert rel_rms(out[1][1], out[0][1]) < 1e-13
+    assert abs(out[1][0][0] - out[0][0][0]) < 1e-13 * abs(out[0][0][0])
+    sp = spec_for(desc)
+    aw, au, ureal = sp.pairs(r, q)
+    eng.set_option("pair_variant", 2)
+    eng.stage_bin(rd, qd)
+    a2 = torch.zeros((N, 3), dtype=torch.float64, device="cuda:0")
+    eng.stage_pairs(a2)
+    assert rel_rms(a2.cpu().numpy(), aw) < TOL
+
+
+def test_conventions(msm, torch):
+    """ACC_LITERAL = msmLibrary.c:168-176 / msmPeriodic.c:1158 weighting, ACC_FORCE = -q_i * gradient."""
+    N, A = 2500, (1.0, 1.0, 1.0)
+    r, q = O.neutral_system(N, A, seed=9)
+    q = q * (1.0 + 0.3 * np.arange(N) / N)  # unequal magnitudes so that the conventions differ
+    base = msm.plan_auto(N, A, 4, 10, 4.0, 1)
+    sp = spec_for(base)
+    ref = sp.eval(r, q)
+    fs = ref["acc"] - ref["along"]
+    want = {msm.capi.ACC_GRADIENT: ref["acc"],
+            msm.capi.ACC_LITERAL: 0.5 * (q[:, None] * ref["fshort_unw"] + fs) + q[:, None] * ref["along"],
+            msm.capi.ACC_FORCE: -q[:, None] * ref["acc"]}
+    for conv, w in want.items():
+        d = msm.plan_auto(N, A, 4, 10, 4.0, 1)
+        d.acc_convention = conv
+        eng = msm.Engine(d)
+        en, acc = eng.eval(r, q)
+        assert rel_rms(acc.cpu().numpy(), w) < TOL
+        eng.close()
+
+
+ALL = ["CsClN2", "NaClN8", "NaNaN8", "changaN8", "CsClN16", "NaClN64", "NaNaN64", "changaN64", "CsClN128",
+       "NaClN512", "NaNaN512", "changaN512"]
+LABELS = (("potential_short_real", "(A) ushort_real"), ("potential_short_self", "(B) ushort_self"),
+          ("potential_short_csr", "(C) ushort_csr"), ("potential_long_real", "(D) ulong_real"),
+          ("potential_long_fourier", "(E) ulong_four"), ("potential_long_self", "(F) ulong_self"),
+          ("potential_total", "utotal"))
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_dropin_msmperiodic_matches_reference(msm, name):
+    """msmperiodic() on the GPU == the reference's msmPeriodic on every system of msm/data (p=4 mu=10 abar=4):
+    parameters, (A)..(F), utotal, msm.acc / msm.acclong / msm.accshort, and the +0.5 shift of the caller's r."""
+    fx, r, q, A = system(name)
+    r_in = r.copy()
+    st, u, f, r_after = msm.msmperiodic(r_in, q, 4, 4.0, 10, A, mode=msm.capi.MODE_LITERAL, quiet=True)
+    assert np.array_equal(r_after, r + 0.5)  # msmPeriodic.c:75-76
+    s = fx["stats"]
+    assert st.Mx == int(s["Mx My Mz"].split()[0]) and st.kmax == int(s["kmax"]) and st.L == 1
+    assert st.beta == float(s["beta"]) and st.a == float(s["a"])
+    comps = [abs(fx["scalars"][lab]) for _, lab in LABELS[:6]]
+    scale = max(comps)
+    for field, lab in LABELS:
+        ref = fx["scalars"][lab]
+        assert abs(getattr(st, field) - ref) <= TOL * scale, (lab, getattr(st, field), ref)
+    assert abs(u - fx["potential"]) <= TOL * scale
+    lit = O.literal_run(r, q, 4, 4.0, 10, A)
+    floor = np.abs(q).max() / lit["a"] ** 2   # one pair term
+    assert rel_rms(f, np.array(fx["acc"]).reshape(-1, 3), floor) < TOL
+    assert rel_rms(f, lit["facc"].reshape(-1, 3), floor) < TOL
+
+
+def test_dropin_stagewise_literal(msm, torch):
+    """Literal mode stage by stage against the literal mirror: grid charges, edir, etop, fshort, flong."""
+    for name in ("changaN64", "CsClN16", "changaN512"):
+        fx, r, q, A = system(name)
+        lit = O.literal_run(r, q, 4, 4.0, 10, A)
+        d = msm.plan_auto(len(q), A, 4, 10, 4.0, 1)
+        d.acc_convention = msm.capi.ACC_LITERAL
+        eng = msm.Engine(d, literal=True)
+        K, first = eng.stencil(0)
+        assert first == lit["slmin"]
+        assert grid_err(K.ravel(), lit["sl"]) < 1e-11
+        rs = r + 0.5
+        eng.stage_bin(torch.as_tensor(rs, device="cuda:0"), torch.as_tensor(q, device="cuda:0"))
+        eng.stage_anterpolate()
+        assert grid_err(eng.grid(msm.capi.GRID_Q, 0).ravel(), lit["qgrd"]) < TOL
+        eng.stage_grid()
+        assert grid_err(eng.grid(msm.capi.GRID_E, 0).ravel(), lit["edir"]) < 1e-11
+        assert grid_err(eng.grid(msm.capi.GRID_EFOUR, 0).ravel(), lit["etop"]) < 1e-11
+        fs = torch.zeros((len(q), 3), dtype=torch.float64, device="cuda:0")
+        fl = torch.zeros_like(fs)
+        eng.stage_pairs(fs)
+        eng.stage_interpolate(fl)
+        floor = np.abs(q).max() / lit["a"] ** 2
+        assert rel_rms(fs.cpu().numpy(), lit["fshort"].reshape(-1, 3), floor) < TOL
+        assert rel_rms(fl.cpu().numpy(), lit["flong"].reshape(-1, 3), floor * 1e-3) < 1e-10
+        eng.close()
+
+
+SIMPLE = [("msmSimple_changaN8_nu4_mu10_M2.json", "changaN8", 1), ("msmSimple_changaN8_nu6_mu10_M2.json", "changaN8", 1),
+          ("msmSimple_changaN8_nu4_mu10_M3.json", "changaN8", 1), ("msmSimple_changaN8_nu6_mu6_M4.json", "changaN8", 1),
+          ("msmSimple_CsClN16_nu4_mu10_M3.json", "CsClN16", 1), ("msmSimple_changaN64_nu4_mu10_M4.json", "changaN8", 2)]
+
+
+@pytest.mark.parametrize("fn,sysname,copies", SIMPLE)
+def test_matches_msmSimple_reference(msm, fn, sysname, copies):
+    """HIP path == the reference's msmSimple (2-level, long-range forces, v=4/6, odd and even grids).
+    msmSimple's own image sums stop at 1e-8 relative change (msmSimple.c:16,1060): 2e-10 on grid terms."""
+    from test_oracle_golden import simple_case
+    fx, r, q, A = simple_case(fn, sysname, copies)
+    sc, args = fx["scalars"], fx["args"]
+    mu, nu, M = args[2], args[3], args[4:7]
+    d = msm.plan_explicit(len(q), A, M, nu, mu, 1, sc["a"], sc["beta"], int(sc["kmax"]))
+    eng = msm.Engine(d)
+    en, acc = eng.eval(r, q)
+    scale = abs(sc["ushort_real"]) + abs(sc["ulong_self"])
+    for i, k in enumerate(["ushort_real", "ushort_self", "ushort_csr", "ulong_real", "ulong_four", "ulong_self", "utotal"]):
+        tol = 1e-12 if k in ("ushort_real", "ushort_self", "ushort_csr", "ulong_self") else 2e-10
+        assert abs(en[i] - sc[k]) <= tol * max(abs(sc[k]), scale * 1e-3), (k, en[i], sc[k])
+    ft = np.array(fx["acc"]["ftotal"]).reshape(-1, 3)
+    assert rel_rms(acc.cpu().numpy(), ft, np.abs(q).max() / sc["a"] ** 2) < 2e-10
+    eng.close()
+
+
+def test_edge_cases(msm, torch):
+    # a single particle: only self terms
+    d = msm.plan_explicit(1, (1.0, 1.0, 1.0), (4, 4, 4), 4, 10, 1, 0.9, 3.0, 6)
+    eng = msm.Engine(d)
+    sp = spec_for(d)
+    r, q = np.array([[0.3, 0.9, 0.5]]), np.array([2.0])
+    en, acc = eng.eval(r, q)
+    ref = sp.eval(r, q)
+    assert np.abs(en - ref["energies"]).max() < TOL * np.abs(ref["energies"][:6]).max()
+    assert np.abs(acc.cpu().numpy() - ref["acc"]).max() < 1e-10 * np.abs(q).max() / 0.81
+    eng.close()
+    # strongly clustered input: most cells empty, one cell crowded (several i-passes per cell)
+    N, A = 4000, (1.0, 1.0, 1.0)
+    rng = np.random.default_rng(4)
+    r = 0.5 + 0.02 * rng.standard_normal((N, 3))
+    r[: N // 4] = rng.random((N // 4, 3))
+    q = np.where(np.arange(N) % 2 == 0, 1.0, -1.0)
+    d = msm.plan_explicit(N, A, (16, 16, 16), 4, 10, 2, 0.22, 6.0, 11)
+    eng = msm.Engine(d)
+    sp = spec_for(d)
+    ref = sp.eval(r, q)
+    for v in (1, 2):
+        eng.set_option("pair_variant", v)
+        en, acc = eng.eval(r, q)
+        assert np.abs(en - ref["energies"]).max() < TOL * np.abs(ref["energies"][:6]).max()
+        assert rel_rms(acc.cpu().numpy(), ref["acc"]) < TOL
+    eng.close()
+    # invalid plans fail loudly
+    bad = msm.plan_explicit(10, (1.0, 1.0, 1.0), (6, 6, 6), 4, 10, 3, 0.3, 3.0, 5)  # 6 not divisible by 4
+    with pytest.raises(msm.MsmAmdError):
+        msm.Engine(bad)
+    bad = msm.plan_explicit(10, (1.0, 1.0, 1.0), (8, 8, 8), 5, 10, 1, 0.3, 3.0, 5)  # p = 5
+    with pytest.raises(msm.MsmAmdError):
+        msm.Engine(bad)
+
+
+def test_full_size_properties(msm, torch):
+    """N = 1M, L = 4 (the benchmark configuration): properties that hold at any size."""
+    N, A = 1000000, (1.0, 1.0, 1.0)
+    r, q = O.neutral_system(N, A, seed=20261111 + 1)
+    desc = msm.plan_auto(N, A, 4, 10, 4.0, 0)
+    assert list(desc.M) == [96, 96, 96] and desc.L == 4
+    eng = msm.Engine(desc)
+    rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
+    en, acc = eng.eval(rd, qd)
+    acc = acc.cpu().numpy()
+    assert np.isfinite(en).all() and np.isfinite(acc).all()
+    # charge conservation through anterpolation and every restriction
+    for l in range(desc.L):
+        assert abs(eng.grid(msm.capi.GRID_Q, l).sum() - q.sum()) < 1e-8
+    # the pair sum is antisymmetric: sum_i q_i acc_short_i = 0; the grid part obeys it to interpolation accuracy
+    eng.stage_bin(rd, qd)
+    a_s = torch.zeros((N, 3), dtype=torch.float64, device="cuda:0")
+    eng.stage_pairs(a_s)
+    tot = (qd[:, None] * a_s).sum(0).cpu().numpy()
+    assert np.abs(tot).max() < 1e-9 * float((qd[:, None] * a_s).abs().sum())
+    # bitwise reproducible
+    en2, acc2 = eng.eval(rd, qd)
+    assert np.array_equal(en, en2) and np.array_equal(acc, acc2.cpu().numpy())
+    # both pair kernels agree at full size
+    eng.set_option("pair_variant", 2)
+    en3, acc3 = eng.eval(rd, qd)
+    assert rel_rms(acc3.cpu().numpy(), acc) < 1e-13
+    # invariance under a lattice translation of some particles and under relabelling
+    r2 = r.copy()
+    r2[::7] += np.array([1.0, -2.0, 3.0])
+    en4, acc4 = eng.eval(torch.as_tensor(r2, device="cuda:0"), qd)
+    assert abs(en4[6] - en3[6]) < 1e-9 * np.abs(en3[:6]).max()
+    perm = np.random.default_rng(0).permutation(N)
+    en5, acc5 = eng.eval(torch.as_tensor(r[perm], device="cuda:0"), torch.as_tensor(q[perm], device="cuda:0"))
+    assert abs(en5[6] - en3[6]) < 1e-10 * np.abs(en3[:6]).max()
+    assert rel_rms(acc5.cpu().numpy(), acc3.cpu().numpy()[perm]) < 1e-10
+    # sampled check of the accelerations against the Ewald sum on a subset (accuracy of the method itself)
+    eng.close()
+
+
+def test_accuracy_vs_ewald_100k(msm, torch):
+    """Config 2 (100k, cubic B-spline, 3 levels): relative energy error and force RMS error against a
+    full Ewald sum evaluated for a random subset of particles."""
+    N, A = 100000, (1.0, 1.0, 1.0)
+    r, q = O.neutral_system(N, A, seed=20261111 + 2)
+    desc = msm.plan_auto(N, A, 4, 10, 4.0, 3)
+    assert list(desc.M) == [48, 48, 48]
+    eng = msm.Engine(desc)
+    en, acc = eng.eval(r, q)
+    acc = acc.cpu().numpy()
+    nsub = 200
+    # put the subset first (or_ewald evaluates the first nsub particles against all N)
+    uE, aE = O.ewald(r, q, A, alpha=20.0, rcut=0.25, kcut=28, nsub=nsub, nthreads=16)
+    ferr = rel_rms(acc[:nsub], aE)
+    assert ferr < 2e-3, ferr
+    eng.close()
