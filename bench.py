@@ -86,6 +86,9 @@ def main():
         from msm_amd.slab import SlabRank
         stepper = SlabRank(torch, dist, msm_amd, desc, r_all, q_all, rank, world, local_rank)
         eng = stepper.eng
+        if args.pair_variant >= 0:
+            eng.set_option("pair_variant", args.pair_variant)
+        stepper.profile = SlabProfiler(torch, stepper).profile
 
     def barrier():
         if dist is not None:
@@ -106,15 +109,9 @@ def main():
         elapsed = float(t.item())
     energies = stepper.last_energies
 
-    # per-kernel durations with HIP events on the engine's stream (separate, untimed pass)
-    eng.set_profiling(True)
-    acc_ms = {}
+    # per-kernel durations with HIP events on the stream the kernels run on (separate, untimed pass)
     nprof = max(3, min(10, args.steps))
-    for _ in range(nprof):
-        stepper.step()
-        for k, v in eng.last_timings().items():
-            acc_ms[k] = acc_ms.get(k, 0.0) + v / nprof
-    eng.set_profiling(False)
+    acc_ms = stepper.profile(nprof)
 
     pairs = N * (4.0 * math.pi / 3.0) * abar ** 3 / world   # ordered in-cutoff pairs handled by one rank's launch
     flops = pairs * FLOP_PER_PAIR[p]
@@ -177,6 +174,41 @@ class SingleGpu:
         self.r.add_(self.delta, alpha=self.sign)
         self.sign = -self.sign
         self.last_energies, _ = self.eng.eval(self.r, self.q, self.acc)
+
+    def profile(self, n):
+        # the engine brackets every stage with hipEventRecord on its own stream
+        self.eng.set_profiling(True)
+        acc = {}
+        for _ in range(n):
+            self.step()
+            for k, v in self.eng.last_timings().items():
+                acc[k] = acc.get(k, 0.0) + v / n
+        self.eng.set_profiling(False)
+        return acc
+
+
+class SlabProfiler:
+    """Stage durations of a slab rank: events recorded on the current (= the engine's, null) stream."""
+
+    def __init__(self, torch, slab):
+        self.torch, self.slab = torch, slab
+
+    def profile(self, n):
+        t = self.torch
+        acc = {}
+        for _ in range(n):
+            evs = []
+
+            def mark(name):
+                e = t.cuda.Event(enable_timing=True)
+                e.record()
+                evs.append((name, e))
+            self.slab.step(marks=mark)
+            t.cuda.synchronize()
+            for (name, e0), (_, e1) in zip(evs[:-1], evs[1:]):
+                acc[name] = acc.get(name, 0.0) + e0.elapsed_time(e1) / n
+            acc["total"] = acc.get("total", 0.0) + evs[0][1].elapsed_time(evs[-1][1]) / n
+        return acc
 
 
 def cpu_baseline(desc, r, q):

@@ -223,6 +223,16 @@ int msm_amd_stage_interpolate(msm_amd_handle *h, double *d_acc);
 /* reductions; energies[MSM_AMD_U_COUNT] host out */
 int msm_amd_stage_energies(msm_amd_handle *h, double *energies);
 
+/* ---- slab ranks (one process per GPU; collectives are the caller's) ---- */
+/* particles of the next evaluation: n_total <= plan N (the capacity), the first n_owned of them owned */
+int msm_amd_set_counts(msm_amd_handle *h, int n_total, int n_owned);
+/* [pair sum, q0.e0 over owned planes, qL.efour, sum q, sum q^2 over owned particles]: additive over ranks
+ * (except the third, which is replicated).  Left on the device; host_out5 != NULL copies them back. */
+int msm_amd_stage_raw_sums(msm_amd_handle *h, double *host_out5);
+void *msm_amd_raw_sums_device_ptr(msm_amd_handle *h);
+/* host arithmetic: energies from raw sums that were added over all ranks */
+int msm_amd_combine_energies(msm_amd_handle *h, const double sums[5], double energies[MSM_AMD_U_COUNT]);
+
 /* device pointers / copies of internal state (for the slab all-gather and the tests) */
 enum { MSM_AMD_GRID_Q = 0, MSM_AMD_GRID_E = 1, MSM_AMD_GRID_EFOUR = 2 };
 void *msm_amd_grid_device_ptr(msm_amd_handle *h, int which, int level);

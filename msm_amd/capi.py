@@ -102,6 +102,10 @@ SIGNATURES = {
     "msm_amd_stage_grid": (C.c_int, [_vp]),
     "msm_amd_stage_interpolate": (C.c_int, [_vp, _vp]),
     "msm_amd_stage_energies": (C.c_int, [_vp, _dp]),
+    "msm_amd_set_counts": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "msm_amd_stage_raw_sums": (C.c_int, [_vp, _dp]),
+    "msm_amd_raw_sums_device_ptr": (_vp, [_vp]),
+    "msm_amd_combine_energies": (C.c_int, [_vp, _dp, _dp]),
     "msm_amd_grid_device_ptr": (_vp, [_vp, C.c_int, C.c_int]),
     "msm_amd_grid_dims": (C.c_int, [_vp, C.c_int, _ip]),
     "msm_amd_copy_grid": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),

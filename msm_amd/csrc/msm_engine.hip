@@ -30,7 +30,7 @@ struct msm_amd_handle {
     HostPlan hp;
     int device = 0;
     hipStream_t stream = nullptr;
-    int N = 0, n_owned = 0;
+    int N = 0, n_owned = 0, capacity = 0;
     bool small_box = false;
     int nc[3] = {0, 0, 0}, ncell = 0;
     BinGeom cellg, gridg;
@@ -108,6 +108,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
     h->device = device;
     h->stream = (hipStream_t)stream;
     h->N = d.N;
+    h->capacity = d.N;
     h->n_owned = (d.n_owned > 0 && d.n_owned <= d.N) ? d.n_owned : d.N;
     const int N = d.N, L = d.L;
 
@@ -145,6 +146,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
     gamma_poly(d.p, pp.cg, pp.cd);
     pp.p = d.p;
     pp.convention = d.acc_convention;
+    pp.n_owned = h->n_owned;
 
     SplineParams &sp = h->sp;
     sp.p = d.p;
@@ -159,6 +161,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
     sp.z0 = d.zplane0;
     sp.nz = d.nzplanes;
     sp.convention = d.acc_convention;
+    sp.n_owned = h->n_owned;
 
 #define DA(ptr, n)                      \
     do {                                \
@@ -232,6 +235,21 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     hipFree(h->s_r); hipFree(h->s_q); hipFree(h->s_acc);
     if (h->ev_made) for (int i = 0; i <= T_COUNT; i++) hipEventDestroy(h->ev[i]);
     delete h;
+}
+
+// A slab rank evaluates a different number of particles every step (owned + halo copies); the plan's N is the
+// capacity the buffers were sized for.
+extern "C" int msm_amd_set_counts(msm_amd_handle *h, int n_total, int n_owned) {
+    if (!h || n_total < 1 || n_total > h->capacity || n_owned < 0 || n_owned > n_total) {
+        set_error("set_counts: need 1 <= n_total <= capacity (%d) and 0 <= n_owned <= n_total", h ? h->capacity : 0);
+        return MSM_AMD_EINVAL;
+    }
+    if (h->small_box && n_owned != n_total) { set_error("set_counts: halo particles need the cell-list path"); return MSM_AMD_EINVAL; }
+    h->N = n_total;
+    h->n_owned = n_owned;
+    h->pp.n_owned = n_owned;
+    h->sp.n_owned = n_owned;
+    return MSM_AMD_OK;
 }
 
 extern "C" void msm_amd_set_profiling(msm_amd_handle *h, int on) {
@@ -324,6 +342,7 @@ extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
             // (interpolation support); other planes of ge[0] are left untouched.
             const int hz = p / 2, Mz = d.M[2];
             int lo = d.zplane0 - hz, n = d.nzplanes + 2 * hz;
+            hipMemsetAsync(h->ge[0], 0, sizeof(double) * (size_t)d.M[0] * d.M[1] * Mz, st);
             if (n >= Mz) { convolve_level(h, 0, h->gq[0], h->ge[0], 0, Mz); }
             else {
                 lo = ((lo % Mz) + Mz) % Mz;
@@ -370,7 +389,7 @@ extern "C" int msm_amd_stage_interpolate(msm_amd_handle *h, double *d_acc) {
     return MSM_AMD_OK;
 }
 
-static int queue_energies(msm_amd_handle *h) {
+static int queue_energies(msm_amd_handle *h, bool raw = false) {
     const msm_amd_plan_desc &d = h->hp.d;
     const int L = d.L;
     const size_t plane = (size_t)d.M[0] * d.M[1];
@@ -388,8 +407,38 @@ static int queue_energies(msm_amd_handle *h) {
     in.csr = h->hp.csr;
     in.gamma0_over_a = h->hp.gamma0 / d.a;
     in.literal = h->hp.literal ? 1 : 0;
-    launch_finalize_energies(h->stream, in, h->d_energies);
+    if (raw) launch_raw_sums(h->stream, in, h->d_energies);
+    else launch_finalize_energies(h->stream, in, h->d_energies);
     HIPCHK(hipGetLastError());
+    return MSM_AMD_OK;
+}
+
+// [pair sum, q0.e0 over the owned planes, qL.efour, sum q, sum q^2 (owned particles)] on the device
+// (msm_amd_raw_sums_device_ptr); host_out5 != NULL additionally copies them back (synchronises).
+extern "C" int msm_amd_stage_raw_sums(msm_amd_handle *h, double *host_out5) {
+    if (!h || !h->cur_q) { set_error("stage_raw_sums: bin first"); return MSM_AMD_EINVAL; }
+    int rc = queue_energies(h, true);
+    if (rc) return rc;
+    if (host_out5) {
+        HIPCHK(hipMemcpyAsync(h->h_energies, h->d_energies, 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        memcpy(host_out5, h->h_energies, 5 * sizeof(double));
+    }
+    return MSM_AMD_OK;
+}
+extern "C" void *msm_amd_raw_sums_device_ptr(msm_amd_handle *h) { return h ? h->d_energies : nullptr; }
+
+// (A)..(F) and the total from raw sums that were added over all slab ranks (host arithmetic, no device work)
+extern "C" int msm_amd_combine_energies(msm_amd_handle *h, const double sums[5], double en[MSM_AMD_U_COUNT]) {
+    if (!h || !sums || !en) return MSM_AMD_EINVAL;
+    const double ulf = 0.5 * sums[2], ulr = 0.5 * sums[1] - ulf;
+    en[MSM_AMD_U_SHORT_REAL] = sums[0];
+    en[MSM_AMD_U_SHORT_SELF] = 0.5 * sums[4] * h->hp.self_image_sum;
+    en[MSM_AMD_U_SHORT_CSR] = -0.5 * sums[3] * sums[3] * h->hp.csr;
+    en[MSM_AMD_U_LONG_REAL] = ulr;
+    en[MSM_AMD_U_LONG_FOUR] = ulf;
+    en[MSM_AMD_U_LONG_SELF] = -0.5 * sums[4] * h->hp.gamma0 / h->hp.d.a;
+    en[MSM_AMD_U_TOTAL] = (ulf + ulr + en[MSM_AMD_U_LONG_SELF]) + (sums[0] + en[MSM_AMD_U_SHORT_SELF] + en[MSM_AMD_U_SHORT_CSR]);
     return MSM_AMD_OK;
 }
 

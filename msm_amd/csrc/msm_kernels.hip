@@ -253,7 +253,8 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_pair_cells(const double4 *__re
     double esum = 0.0;
     for (int ib = i0; ib < i1; ib += PAIR_THREADS) {
         const int ii = ib + tid;
-        const bool active = ii < i1;
+        const int orig = ii < i1 ? order[ii] : 0x7fffffff;
+        const bool active = orig < pp.n_owned;
         double4 pi = active ? ps[ii] : make_double4(0, 0, 0, 0);
         double u = 0, fwx = 0, fwy = 0, fwz = 0, fux = 0, fuy = 0, fuz = 0;
         for (int nb = 0; nb < 27; nb++) {
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_pair_cells(const double4 *__re
             }
         }
         if (active) {
-            store_acc(acc, order[ii], pp.convention, pi.w, fwx, fwy, fwz, fux, fuy, fuz);
+            store_acc(acc, orig, pp.convention, pi.w, fwx, fwy, fwz, fux, fuy, fuz);
             esum += 0.5 * pi.w * u;
         }
     }
@@ -313,7 +314,8 @@ __global__ __launch_bounds__(PAIR2_THREADS) void k_pair_cells2(const double4 *__
     double esum = 0.0;
     for (int ib = i0; ib < i1; ib += PAIR2_THREADS) {
         const int ii = ib + tid;
-        const bool active = ii < i1;
+        const int orig = ii < i1 ? order[ii] : 0x7fffffff;
+        const bool active = orig < pp.n_owned;
         double4 pi = active ? ps[ii] : make_double4(1e300, 1e300, 1e300, 0);
         double u = 0, fwx = 0, fwy = 0, fwz = 0, fux = 0, fuy = 0, fuz = 0;
         // the 27 neighbours form 9 rows of 3 x-adjacent cells; rows are contiguous in memory unless they wrap
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(PAIR2_THREADS) void k_pair_cells2(const double4 *__
             }
         }
         if (active) {
-            store_acc(acc, order[ii], pp.convention, pi.w, fwx, fwy, fwz, fux, fuy, fuz);
+            store_acc(acc, orig, pp.convention, pi.w, fwx, fwy, fwz, fux, fuy, fuz);
             esum += 0.5 * pi.w * u;
         }
     }
@@ -531,6 +533,8 @@ __global__ __launch_bounds__(256) void k_interp(const double4 *__restrict__ ps, 
                                                 double *__restrict__ acc) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
+    const int orig = order[k];
+    if (orig >= sp.n_owned) return;
     const double4 pt = ps[k];
     const int Mx = sp.M[0], My = sp.M[1], Mz = sp.M[2];
     double w[3][P], dw[3][P];
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(256) void k_interp(const double4 *__restrict__ ps, 
     double f = 1.0;
     if (sp.convention == MSM_AMD_ACC_LITERAL) f = pt.w;      // msmPeriodic.c:1158-1160
     else if (sp.convention == MSM_AMD_ACC_FORCE) f = -pt.w;
-    const size_t o = 3 * (size_t)order[k];
+    const size_t o = 3 * (size_t)orig;
     acc[o] += f * gx;
     acc[o + 1] += f * gy;
     acc[o + 2] += f * gz;
@@ -895,6 +899,18 @@ __global__ __launch_bounds__(256) void k_finalize_energies(EnergyInputs in, doub
         out[MSM_AMD_U_TOTAL] = (ulf + ulr + out[MSM_AMD_U_LONG_SELF]) +
                                (ua + out[MSM_AMD_U_SHORT_SELF] + out[MSM_AMD_U_SHORT_CSR]);
     }
+}
+__global__ __launch_bounds__(256) void k_raw_sums(EnergyInputs in, double *__restrict__ out) {
+    __shared__ double red[256];
+    const double ua = sum_array(in.pair_parts, in.n_pair, red);
+    const double qe = sum_array(in.grid_parts, in.n_grid, red);
+    const double qf = sum_array(in.four_parts, in.n_four, red);
+    const double qs = sum_array(in.charge_parts, in.n_charge, red);
+    const double qs2 = sum_array(in.charge_parts + in.n_charge, in.n_charge, red);
+    if (threadIdx.x == 0) { out[0] = ua; out[1] = qe; out[2] = qf; out[3] = qs; out[4] = qs2; }
+}
+void launch_raw_sums(hipStream_t st, const EnergyInputs &in, double *out5) {
+    hipLaunchKernelGGL(k_raw_sums, dim3(1), dim3(256), 0, st, in, out5);
 }
 void launch_finalize_energies(hipStream_t st, const EnergyInputs &in, double *out7) {
     hipLaunchKernelGGL(k_finalize_energies, dim3(1), dim3(256), 0, st, in, out7);

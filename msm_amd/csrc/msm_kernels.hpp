@@ -26,6 +26,7 @@ struct PairParams {
     double cd[8];    // -gamma'(rho)/rho = sum cd[k] y^k
     int p;
     int convention;  // MSM_AMD_ACC_*
+    int n_owned;     // particles with original index >= n_owned are halo copies: no output for them
 };
 
 struct GridGeom {
@@ -41,6 +42,7 @@ struct SplineParams {
     int drop_last[3];  // literal anterpolation on odd M leaves the last plane empty (msmPeriodic.c:697-702)
     int z0, nz;        // owned z planes [z0, z0+nz)
     int convention;
+    int n_owned;
 };
 
 // ---- binning ----
@@ -84,5 +86,7 @@ struct EnergyInputs {
     int literal;                                // sign / bookkeeping of msmPeriodic.c:1002,1334-1359
 };
 void launch_finalize_energies(hipStream_t st, const EnergyInputs &in, double *out7);
+// raw sums for a slab rank: out5 = [pair sum, q0.e0 over owned planes, qL.efour, sum q, sum q^2]
+void launch_raw_sums(hipStream_t st, const EnergyInputs &in, double *out5);
 
 } // namespace msm

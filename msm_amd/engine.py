@@ -158,6 +158,35 @@ class Engine:
         check(load().msm_amd_stage_energies(self._h, en.ctypes.data_as(_dp)), "stage_energies")
         return en
 
+    # ---- slab ranks ----
+    def tensor_device(self):
+        return "cuda:%d" % self.device
+
+    def set_counts(self, n_total, n_owned):
+        check(load().msm_amd_set_counts(self._h, int(n_total), int(n_owned)), "set_counts")
+        self.N = int(n_total)
+
+    def stage_raw_sums(self):
+        """Queue the raw sums [pair, q0.e0 (owned planes), qL.efour, sum q, sum q^2]; they stay on the device."""
+        check(load().msm_amd_stage_raw_sums(self._h, None), "stage_raw_sums")
+
+    def raw_sums_tensor(self):
+        return self._wrap(load().msm_amd_raw_sums_device_ptr(self._h), (5,))
+
+    def combine_energies(self, sums):
+        s = np.ascontiguousarray(sums, dtype=np.float64)
+        en = np.zeros(capi.U_COUNT)
+        check(load().msm_amd_combine_energies(self._h, s.ctypes.data_as(_dp), en.ctypes.data_as(_dp)), "combine_energies")
+        return en
+
+    def _wrap(self, ptr, shape):
+        """Zero-copy float64 torch view of device memory owned by the handle."""
+        class _Wrap:
+            pass
+        w = _Wrap()
+        w.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+        return self.torch.as_tensor(w, device="cuda:%d" % self.device)
+
     # ---- state ----
     def grid_dims(self, level):
         d = (C.c_int * 3)()
@@ -176,18 +205,9 @@ class Engine:
 
     def grid_tensor(self, which, level=0):
         """Zero-copy torch view of an internal grid (used by the slab all-gather)."""
-        import ctypes
-        t = self.torch
         d = self.grid_dims(self.L - 1 if which == capi.GRID_EFOUR else level)
         ptr = load().msm_amd_grid_device_ptr(self._h, which, level)
-        n = d[0] * d[1] * d[2]
-        # wrap the raw pointer through the CUDA array interface
-        class _Wrap:
-            pass
-        w = _Wrap()
-        w.__cuda_array_interface__ = {"shape": (d[2], d[1], d[0]), "typestr": "<f8", "data": (int(ptr), False),
-                                      "version": 2}
-        return t.as_tensor(w, device="cuda:%d" % self.device)
+        return self._wrap(ptr, (d[2], d[1], d[0]))
 
     def stencil(self, level):
         size = (C.c_int * 3)()

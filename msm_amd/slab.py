@@ -1,0 +1,138 @@
+"""z-slab decomposition of one periodic MSM evaluation over the GPUs of a node (one process per GPU).
+
+Rank k owns the level-0 grid planes [k*Mz/W, (k+1)*Mz/W) and the particles whose wrapped z lies in that slab;
+it also holds read-only halo copies of the particles within max(a, p/2*hz) of the slab, so the pair sum and the
+anterpolation gather of the owned planes need no communication.  Per evaluation there are exactly two
+collectives (RCCL over xGMI when the backend is "nccl"):
+
+  1. all-gather of the owned planes of the level-0 charge grid (each rank then holds the whole grid; the
+     coarser levels are restricted and solved redundantly because they are too small to shard), issued
+     asynchronously so that it overlaps the pair kernel, which does not depend on it;
+  2. all-reduce of five scalars (pair energy, q.e over owned planes, Fourier term, sum q, sum q^2).
+
+The level-0 convolution — the only grid stage with real work — is evaluated by each rank on its own planes
+plus p/2 planes either side (the interpolation support), so potentials need no halo exchange either.
+"""
+import copy
+
+import numpy as np
+
+from . import capi
+
+
+def slab_planes(Mz, world, rank):
+    """First owned level-0 plane and the number of owned planes of `rank`."""
+    if Mz % world != 0:
+        raise ValueError("the level-0 grid has %d z planes, not divisible by %d ranks" % (Mz, world))
+    nz = Mz // world
+    return rank * nz, nz
+
+
+def select_slab(r, Az, Mz, world, rank, halo):
+    """Indices of the particles `rank` owns and of its halo copies.
+
+    Ownership is decided from the wrapped fractional z alone, with the same expression on every rank, so every
+    particle is owned exactly once.  halo is a physical distance (periodic in z)."""
+    z0, nz = slab_planes(Mz, world, rank)
+    zf = np.asarray(r)[:, 2] / Az
+    zf = zf - np.floor(zf)
+    lo, hi = z0 / Mz, (z0 + nz) / Mz
+    owned = (zf >= lo) & (zf < hi)
+    hf = halo / Az
+    below = np.mod(lo - zf, 1.0)   # periodic distance below the slab
+    above = np.mod(zf - hi, 1.0)   # periodic distance above the slab
+    halo_mask = (~owned) & ((below <= hf) | (above < hf))
+    return np.nonzero(owned)[0], np.nonzero(halo_mask)[0]
+
+
+def halo_width(desc, margin=0.0):
+    hz = desc.A[2] / desc.M[2]
+    return max(desc.a, (desc.p / 2) * hz) + margin
+
+
+class SlabRank:
+    """One rank of a slab-decomposed evaluation.  `engine_factory(desc)` returns an object with the Engine
+    interface (tests inject a CPU stand-in to exercise the partition and collective logic without a GPU)."""
+
+    def __init__(self, torch, dist, msm_amd, desc, r_all, q_all, rank, world, local_rank=0, margin=2e-4,
+                 engine_factory=None, perturb=True):
+        self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+        self.z0, self.nz = slab_planes(desc.M[2], world, rank)
+        own, hal = select_slab(r_all, desc.A[2], desc.M[2], world, rank, halo_width(desc, margin if perturb else 0.0))
+        self.own_idx, self.halo_idx = own, hal
+        n_own, n_tot = len(own), len(own) + len(hal)
+        d = copy.copy(desc)
+        d.N = int(n_tot * 1.02) + 64       # capacity; the counts of a step are set with set_counts
+        d.zplane0, d.nzplanes, d.n_owned = self.z0, self.nz, 0
+        self.eng = engine_factory(d) if engine_factory else msm_amd.Engine(d, device=local_rank)
+        self.eng.set_counts(n_tot, n_own)
+        idx = np.concatenate([own, hal])
+        dev = self.eng.tensor_device()
+        self.r = torch.as_tensor(np.ascontiguousarray(np.asarray(r_all)[idx]), device=dev)
+        self.q = torch.as_tensor(np.ascontiguousarray(np.asarray(q_all)[idx]), device=dev)
+        self.acc = torch.zeros((n_tot, 3), dtype=torch.float64, device=dev)
+        self.n_own, self.n_tot = n_own, n_tot
+        self.q0 = self.eng.grid_tensor(capi.GRID_Q, 0)          # (Mz, My, Mx) view of the engine's level-0 charges
+        self.send = torch.empty_like(self.q0[self.z0:self.z0 + self.nz])
+        self.sums = self.eng.raw_sums_tensor()
+        self.perturb = perturb
+        if perturb:
+            g = torch.Generator(device=dev)
+            g.manual_seed(7 + rank)
+            self.delta = (torch.rand(self.r.shape, generator=g, dtype=torch.float64, device=dev) - 0.5) * margin
+            self.sign = 1.0
+        self.last_energies = None
+
+    def _host_staged(self):
+        # a gloo group cannot move device memory: stage through the host (functional testing on one GPU)
+        return self.dist.get_backend() == "gloo" and self.q0.is_cuda
+
+    def _all_gather_planes(self, async_op):
+        self.send.copy_(self.q0[self.z0:self.z0 + self.nz])
+        if self._host_staged():
+            parts = [self.torch.empty(self.send.shape, dtype=self.torch.float64) for _ in range(self.world)]
+            self.dist.all_gather(parts, self.send.cpu())
+            for k in range(self.world):
+                self.q0[k * self.nz:(k + 1) * self.nz].copy_(parts[k])
+            return None
+        try:
+            return self.dist.all_gather_into_tensor(self.q0.view(-1), self.send.view(-1), async_op=async_op)
+        except (RuntimeError, NotImplementedError):
+            parts = [self.q0[k * self.nz:(k + 1) * self.nz] for k in range(self.world)]
+            return self.dist.all_gather(parts, self.send, async_op=async_op)
+
+    def step(self, marks=None):
+        """One evaluation.  marks: optional callable(name) invoked between stages (bench.py records events)."""
+        eng = self.eng
+        mark = marks if marks is not None else (lambda name: None)
+        if self.perturb:
+            self.r.add_(self.delta, alpha=self.sign)
+            self.sign = -self.sign
+        mark("bin")
+        eng.stage_bin(self.r, self.q)
+        mark("anterpolation")
+        eng.stage_anterpolate()
+        mark("allgather_issue")
+        work = self._all_gather_planes(async_op=True)
+        mark("pairs")
+        eng.stage_pairs(self.acc)          # independent of the gather: runs while the planes travel
+        mark("allgather_wait")
+        if work is not None:
+            work.wait()
+        mark("grid")
+        eng.stage_grid()
+        mark("interpolation")
+        eng.stage_interpolate(self.acc)
+        mark("reductions")
+        eng.stage_raw_sums()
+        mark("end")
+        s = self.sums.clone()
+        s[2] = s[2] / self.world           # the Fourier term is replicated on every rank
+        if self._host_staged():
+            s = s.cpu()
+        self.dist.all_reduce(s)
+        self.last_energies = eng.combine_energies(s.cpu().numpy())
+        return self.last_energies
+
+    def owned_acc(self):
+        return self.acc[:self.n_own]

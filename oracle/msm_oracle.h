@@ -104,6 +104,8 @@ int or_spec_eval(or_spec_plan *pl, const double *r, const double *q, double *acc
                  double *energies, double *seconds);
 /* stage entry points used for stage-wise parity tests */
 void or_spec_pairs(const or_spec_plan *pl, const double *r, const double *q, double *acc_w, double *acc_unw, double *u_real);
+void or_spec_pairs_ex(const or_spec_plan *pl, const double *r, const double *q, double *acc_w, double *acc_unw,
+                      double *u_real, double *phi);
 void or_spec_anterpolate(const or_spec_plan *pl, const double *r, const double *q, double *grid);
 void or_spec_restrict(const or_spec_plan *pl, int l, const double *fine, double *coarse);
 void or_spec_prolong_add(const or_spec_plan *pl, int l, const double *coarse, double *fine);

@@ -266,6 +266,12 @@ static inline void pair_term(double dx, double dy, double dz, double r2, double 
 
 void or_spec_pairs(const or_spec_plan *pl, const double *r, const double *q, double *acc_w, double *acc_unw,
                    double *u_real) {
+    or_spec_pairs_ex(pl, r, q, acc_w, acc_unw, u_real, NULL);
+}
+
+/* same, and phi[i] = sum_j q_j sum_P g0 (the short-range potential at particle i) when phi != NULL */
+void or_spec_pairs_ex(const or_spec_plan *pl, const double *r, const double *q, double *acc_w, double *acc_unw,
+                      double *u_real, double *phi) {
     const or_spec_params *P = &pl->prm;
     int N = P->N, nc[3], d, i;
     double a = P->a, a2 = a * a, usum = 0.0;
@@ -292,6 +298,7 @@ void or_spec_pairs(const or_spec_plan *pl, const double *r, const double *q, dou
                         }
             }
             usum += 0.5 * q[i] * ui;
+            if (phi) phi[i] = ui;
             for (d = 0; d < 3; d++) {
                 if (acc_w) acc_w[3 * i + d] = fw[d];
                 if (acc_unw) acc_unw[3 * i + d] = fu[d];
@@ -352,6 +359,7 @@ void or_spec_pairs(const or_spec_plan *pl, const double *r, const double *q, dou
                             }
                         }
                 usum += 0.5 * xs[4 * (size_t)ii + 3] * ui;
+                if (phi) phi[order[ii]] = ui;
                 for (dd = 0; dd < 3; dd++) {
                     if (acc_w) acc_w[3 * order[ii] + dd] = fw[dd];
                     if (acc_unw) acc_unw[3 * order[ii] + dd] = fu[dd];

@@ -116,6 +116,8 @@ def lib():
     L.or_spec_eval.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
     L.or_spec_pairs.restype = None
     L.or_spec_pairs.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp]
+    L.or_spec_pairs_ex.restype = None
+    L.or_spec_pairs_ex.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp]
     L.or_spec_anterpolate.restype = None
     L.or_spec_anterpolate.argtypes = [C.c_void_p, _dp, _dp, _dp]
     L.or_spec_restrict.restype = None
@@ -264,6 +266,16 @@ class SpecPlan:
         u = C.c_double(0)
         lib().or_spec_pairs(self.h, rp, qp, aw.ctypes.data_as(_dp), au.ctypes.data_as(_dp), C.byref(u))
         return aw.reshape(n, 3), au.reshape(n, 3), u.value
+
+    def pairs_phi(self, r, q):
+        r, rp = _arr(r)
+        q, qp = _arr(q)
+        n = self.N
+        aw = np.zeros(3 * n)
+        phi = np.zeros(n)
+        u = C.c_double(0)
+        lib().or_spec_pairs_ex(self.h, rp, qp, aw.ctypes.data_as(_dp), None, C.byref(u), phi.ctypes.data_as(_dp))
+        return aw.reshape(n, 3), phi
 
     def anterpolate(self, r, q):
         r, rp = _arr(r)
