@@ -57,7 +57,7 @@ struct msm_amd_handle {
     hipEvent_t ev[T_COUNT + 1];
     bool ev_made = false;
     double last_ms[T_COUNT];
-    int opt_pair_variant = 1, opt_conv_tiled = 1;
+    int opt_pair_variant = 1, opt_conv_tiled = 1, opt_conv_small = 1;
 };
 
 static int g_mode = MSM_AMD_MODE_AUTO;
@@ -266,6 +266,7 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!h || !key) return MSM_AMD_EINVAL;
     if (!strcmp(key, "pair_variant")) { h->opt_pair_variant = value; return MSM_AMD_OK; }
     if (!strcmp(key, "conv_tiled")) { h->opt_conv_tiled = value; return MSM_AMD_OK; }
+    if (!strcmp(key, "conv_small")) { h->opt_conv_small = value; return MSM_AMD_OK; }
     set_error("unknown option %s", key);
     return MSM_AMD_EINVAL;
 }
@@ -309,6 +310,14 @@ extern "C" int msm_amd_stage_anterpolate(msm_amd_handle *h) {
     return MSM_AMD_OK;
 }
 
+// thread-per-node for big outputs, wave-per-node when the grid is too small to fill the chip that way
+static void conv_untiled(msm_amd_handle *h, const double *q, const double *K, const int M[3], const int ks[3],
+                         const int kf[3], double *e, int z0, int nz) {
+    const long nout = (long)M[0] * M[1] * nz, taps = (long)ks[0] * ks[1] * ks[2];
+    if (h->opt_conv_small && nout <= 65536 && taps >= 256) launch_conv_small(h->stream, q, K, M, ks, kf, e, z0, nz, 0);
+    else launch_conv_direct(h->stream, q, K, M, ks, kf, e, z0, nz, 0);
+}
+
 static void convolve_level(msm_amd_handle *h, int l, const double *q, double *e, int z0, int nz) {
     const LevelStencil &S = h->hp.K[l];
     if (h->hp.literal) {
@@ -318,7 +327,7 @@ static void convolve_level(msm_amd_handle *h, int l, const double *q, double *e,
     // the tiled kernel pays off once the grid is much larger than the stencil
     const bool big = h->hp.Ml[l][0] >= 16 && h->hp.Ml[l][1] >= 8 && nz >= 8;
     if (h->opt_conv_tiled && big && launch_conv_tiled(h->stream, q, h->dKt[l], h->hp.Ml[l], S.size, S.first, e, z0, nz)) return;
-    launch_conv_direct(h->stream, q, h->dK[l], h->hp.Ml[l], S.size, S.first, e, z0, nz, 0);
+    conv_untiled(h, q, h->dK[l], h->hp.Ml[l], S.size, S.first, e, z0, nz);
 }
 
 extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
@@ -363,7 +372,7 @@ extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
             launch_conv_literal(st, h->gq[L - 1], h->dKL, ML, h->hp.KL.size, h->hp.KL.first, h->efour);
             // the reference then overwrites elng with edir (msmPeriodic.c:1006-1011): nothing is added
         } else {
-            launch_conv_direct(st, h->gq[L - 1], h->dKL, ML, h->hp.KL.size, h->hp.KL.first, h->efour, 0, ML[2], 0);
+            conv_untiled(h, h->gq[L - 1], h->dKL, ML, h->hp.KL.size, h->hp.KL.first, h->efour, 0, ML[2]);
             launch_axpy(st, h->ge[L - 1], h->efour, nL);
         }
     }
@@ -592,7 +601,7 @@ extern "C" int msm_amd_op_convolve(msm_amd_handle *h, int l, const double *d_q, 
     if (!h || l < 0 || l > h->hp.d.L) { set_error("op_convolve: level out of range"); return MSM_AMD_EINVAL; }
     if (l == h->hp.d.L) {
         const int *ML = h->hp.Ml[l - 1];
-        launch_conv_direct(h->stream, d_q, h->dKL, ML, h->hp.KL.size, h->hp.KL.first, d_e, 0, ML[2], 0);
+        conv_untiled(h, d_q, h->dKL, ML, h->hp.KL.size, h->hp.KL.first, d_e, 0, ML[2]);
     } else {
         convolve_level(h, l, d_q, d_e, 0, h->hp.Ml[l][2]);
     }

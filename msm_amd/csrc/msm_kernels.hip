@@ -365,6 +365,251 @@ __global__ __launch_bounds__(PAIR2_THREADS) void k_pair_cells2(const double4 *__
     if (tid == 0) epart[cell] = tot;
 }
 
+// Variant 3.  One wave per cell.
+//  * main part: lane = one of the first 64 particles of the cell.  The 27 neighbour cells are walked as 9 rows;
+//    a row of 3 x-adjacent cells is one contiguous run of the sorted array (unless it wraps in x), staged in LDS
+//    in tiles of up to 256 candidates.  Phase 1 (cheap distance test, candidate broadcast to all lanes) appends
+//    survivors to a per-lane list; phase 2 runs the kernel on survivors only.  Longer tiles make the per-lane
+//    survivor counts more even, so fewer lanes idle in phase 2.
+//  * overflow part: a cell with more than 64 particles does not get a second, mostly empty, lane-per-particle pass;
+//    each extra particle is handled by the whole wave with lane = candidate and a butterfly reduction.
+#define PAIR3_THREADS 64
+#define PAIR3_TJ 256
+#define PAIR3_LIST 64
+
+struct RowSeg { int j0, j1; double sx, sy, sz; };
+
+// segments (contiguous runs of the sorted array with one periodic shift) of neighbour row `row` (0..8) of a cell
+__device__ __forceinline__ int row_segments(const PairParams &pp, const int *__restrict__ cstart, int cx, int cy, int cz,
+                                            int row, RowSeg seg[3]) {
+    int ny = cy + (row % 3) - 1, nz = cz + (row / 3) - 1;
+    double sy = 0, sz = 0;
+    if (ny < 0) { ny += pp.nc[1]; sy = -pp.A[1]; } else if (ny >= pp.nc[1]) { ny -= pp.nc[1]; sy = pp.A[1]; }
+    if (nz < 0) { nz += pp.nc[2]; sz = -pp.A[2]; } else if (nz >= pp.nc[2]) { nz -= pp.nc[2]; sz = pp.A[2]; }
+    const int base = (nz * pp.nc[1] + ny) * pp.nc[0];
+    if (cx >= 1 && cx <= pp.nc[0] - 2) {
+        seg[0].j0 = cstart[base + cx - 1]; seg[0].j1 = cstart[base + cx + 2];
+        seg[0].sx = 0; seg[0].sy = sy; seg[0].sz = sz;
+        return 1;
+    }
+    for (int o = -1; o <= 1; o++) {
+        int nx = cx + o;
+        double sx = 0;
+        if (nx < 0) { nx += pp.nc[0]; sx = -pp.A[0]; } else if (nx >= pp.nc[0]) { nx -= pp.nc[0]; sx = pp.A[0]; }
+        seg[o + 1].j0 = cstart[base + nx]; seg[o + 1].j1 = cstart[base + nx + 1];
+        seg[o + 1].sx = sx; seg[o + 1].sy = sy; seg[o + 1].sz = sz;
+    }
+    return 3;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <int P, bool UNW>
+__global__ __launch_bounds__(PAIR3_THREADS) void k_pair_cells3(const double4 *__restrict__ ps, const int *__restrict__ cstart,
+                                                               const int *__restrict__ order, PairParams pp,
+                                                               double *__restrict__ acc, double *__restrict__ epart) {
+    __shared__ double4 tile[PAIR3_TJ];
+    __shared__ unsigned char list[PAIR3_LIST][PAIR3_THREADS];
+    const int tid = threadIdx.x;
+    const int cell = xcd_remap(blockIdx.x, gridDim.x);
+    const int cx = cell % pp.nc[0], cy = (cell / pp.nc[0]) % pp.nc[1], cz = cell / (pp.nc[0] * pp.nc[1]);
+    const int i0 = cstart[cell], i1 = cstart[cell + 1];
+    const int imain = min(i1, i0 + PAIR3_THREADS);
+    double esum = 0.0;
+    if (i1 > i0) {
+        const int ii = i0 + tid;
+        const int orig = ii < imain ? order[ii] : 0x7fffffff;
+        const bool active = orig < pp.n_owned;
+        const double4 pi = active ? ps[ii] : make_double4(1e300, 1e300, 1e300, 0);
+        double u = 0, fwx = 0, fwy = 0, fwz = 0, fux = 0, fuy = 0, fuz = 0;
+        for (int row = 0; row < 9; row++) {
+            RowSeg seg[3];
+            const int nseg = row_segments(pp, cstart, cx, cy, cz, row, seg);
+            for (int s = 0; s < nseg; s++) {
+                const double xi = pi.x - seg[s].sx, yi = pi.y - seg[s].sy, zi = pi.z - seg[s].sz;
+                for (int jb = seg[s].j0; jb < seg[s].j1; jb += PAIR3_TJ) {
+                    const int cnt = min(PAIR3_TJ, seg[s].j1 - jb);
+                    __syncthreads();
+                    for (int t = tid; t < cnt; t += PAIR3_THREADS) tile[t] = ps[jb + t];
+                    __syncthreads();
+                    int k = 0;
+                    while (k < cnt) {
+                        int n = 0;
+                        for (; k < cnt && n < PAIR3_LIST; k++) {
+                            const double4 pj = tile[k];
+                            const double dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;
+                            const double r2 = fma(dx, dx, fma(dy, dy, dz * dz));
+                            if (r2 < pp.a2 && (jb + k) != ii) { list[n][tid] = (unsigned char)k; n++; }
+                        }
+                        for (int e = 0; e < n; e++) {
+                            const double4 pj = tile[list[e][tid]];
+                            const double dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;
+                            const double r2 = fma(dx, dx, fma(dy, dy, dz * dz));
+                            pair_term<P, UNW>(dx, dy, dz, r2, pj.w, pp, u, fwx, fwy, fwz, fux, fuy, fuz);
+                        }
+                    }
+                }
+            }
+        }
+        if (active) {
+            store_acc(acc, orig, pp.convention, pi.w, fwx, fwy, fwz, fux, fuy, fuz);
+            esum += 0.5 * pi.w * u;
+        }
+    }
+    // overflow particles: the wave works on one particle at a time, lane = candidate
+    for (int ii = imain; ii < i1; ii++) {
+        const int orig = order[ii];
+        if (orig >= pp.n_owned) continue;
+        const double4 pi = ps[ii];
+        double u = 0, fwx = 0, fwy = 0, fwz = 0, fux = 0, fuy = 0, fuz = 0;
+        for (int row = 0; row < 9; row++) {
+            RowSeg seg[3];
+            const int nseg = row_segments(pp, cstart, cx, cy, cz, row, seg);
+            for (int s = 0; s < nseg; s++) {
+                const double xi = pi.x - seg[s].sx, yi = pi.y - seg[s].sy, zi = pi.z - seg[s].sz;
+                for (int j = seg[s].j0 + tid; j < seg[s].j1; j += PAIR3_THREADS) {
+                    const double4 pj = ps[j];
+                    const double dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;
+                    const double r2 = fma(dx, dx, fma(dy, dy, dz * dz));
+                    if (r2 < pp.a2 && j != ii) pair_term<P, UNW>(dx, dy, dz, r2, pj.w, pp, u, fwx, fwy, fwz, fux, fuy, fuz);
+                }
+            }
+        }
+        u = wave_sum(u); fwx = wave_sum(fwx); fwy = wave_sum(fwy); fwz = wave_sum(fwz);
+        if (UNW) { fux = wave_sum(fux); fuy = wave_sum(fuy); fuz = wave_sum(fuz); }
+        if (tid == 0) {
+            store_acc(acc, orig, pp.convention, pi.w, fwx, fwy, fwz, fux, fuy, fuz);
+            esum += 0.5 * pi.w * u;
+        }
+    }
+    esum = wave_sum(esum);
+    if (tid == 0) epart[cell] = esum;
+}
+
+// Variant 4.  As variant 3, but the distance filter runs in FP32 on coordinates relative to the cell origin and
+// produces a per-lane hit bitmask for 64 candidates at a time: no branches, no LDS writes, every LDS read of the
+// unrolled block can be in flight together.  The FP32 test uses a cutoff inflated by 1e-5 (coordinates relative
+// to the cell are at most 2a in size, so the FP32 error of r^2 is below 1e-6 a^2); phase 2 recomputes the
+// distance in FP64 and applies the exact cutoff, so the result does not depend on the filter's rounding.
+#define PAIR4_THREADS 64
+#define PAIR4_TJ 256
+
+template <int P, bool UNW>
+__global__ __launch_bounds__(PAIR4_THREADS) void k_pair_cells4(const double4 *__restrict__ ps, const int *__restrict__ cstart,
+                                                               const int *__restrict__ order, PairParams pp,
+                                                               double *__restrict__ acc, double *__restrict__ epart) {
+    __shared__ double4 tile[PAIR4_TJ];
+    __shared__ float4 tilef[PAIR4_TJ];
+    const int tid = threadIdx.x;
+    const int cell = xcd_remap(blockIdx.x, gridDim.x);
+    const int cx = cell % pp.nc[0], cy = (cell / pp.nc[0]) % pp.nc[1], cz = cell / (pp.nc[0] * pp.nc[1]);
+    const int i0 = cstart[cell], i1 = cstart[cell + 1];
+    const int imain = min(i1, i0 + PAIR4_THREADS);
+    const double ox = cx * (pp.A[0] / pp.nc[0]), oy = cy * (pp.A[1] / pp.nc[1]), oz = cz * (pp.A[2] / pp.nc[2]);
+    const float a2f = (float)pp.a2 * 1.00001f;
+    double esum = 0.0;
+    if (i1 > i0) {
+        const int ii = i0 + tid;
+        const int orig = ii < imain ? order[ii] : 0x7fffffff;
+        const bool active = orig < pp.n_owned;
+        const double4 pi = active ? ps[ii] : make_double4(1e300, 1e300, 1e300, 0);
+        const float fxi = active ? (float)(pi.x - ox) : 1e30f, fyi = active ? (float)(pi.y - oy) : 1e30f,
+                    fzi = active ? (float)(pi.z - oz) : 1e30f;
+        double u = 0, fwx = 0, fwy = 0, fwz = 0, fux = 0, fuy = 0, fuz = 0;
+        for (int row = 0; row < 9; row++) {
+            RowSeg seg[3];
+            const int nseg = row_segments(pp, cstart, cx, cy, cz, row, seg);
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                if (s >= nseg) break;
+                const double sx = seg[s].sx, sy = seg[s].sy, sz = seg[s].sz;
+                const double xi = pi.x - sx, yi = pi.y - sy, zi = pi.z - sz;
+                for (int jb = seg[s].j0; jb < seg[s].j1; jb += PAIR4_TJ) {
+                    const int cnt = min(PAIR4_TJ, seg[s].j1 - jb);
+                    const int cnt64 = (cnt + 63) & ~63;
+                    __syncthreads();
+                    for (int t = tid; t < cnt64; t += PAIR4_THREADS) {
+                        if (t < cnt) {
+                            const double4 pj = ps[jb + t];
+                            tile[t] = pj;
+                            tilef[t] = make_float4((float)(pj.x + sx - ox), (float)(pj.y + sy - oy), (float)(pj.z + sz - oz), 0.f);
+                        } else {
+                            tilef[t] = make_float4(-1e30f, -1e30f, -1e30f, 0.f);
+                        }
+                    }
+                    __syncthreads();
+                    for (int c0 = 0; c0 < cnt64; c0 += 64) {
+                        unsigned m0 = 0u, m1 = 0u;
+#pragma unroll
+                        for (int k = 0; k < 32; k++) {
+                            const float4 f = tilef[c0 + k];
+                            const float dx = fxi - f.x, dy = fyi - f.y, dz = fzi - f.z;
+                            const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+                            m0 |= (r2 < a2f) ? (1u << k) : 0u;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 32; k++) {
+                            const float4 f = tilef[c0 + 32 + k];
+                            const float dx = fxi - f.x, dy = fyi - f.y, dz = fzi - f.z;
+                            const float r2 = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+                            m1 |= (r2 < a2f) ? (1u << k) : 0u;
+                        }
+                        const int self = ii - (jb + c0); // a particle is not its own neighbour
+                        if (self >= 0 && self < 32) m0 &= ~(1u << self);
+                        else if (self >= 32 && self < 64) m1 &= ~(1u << (self - 32));
+                        while (m0 | m1) {
+                            int k;
+                            if (m0) { k = __ffs(m0) - 1; m0 &= m0 - 1; }
+                            else { k = 31 + __ffs(m1); m1 &= m1 - 1; }
+                            const double4 pj = tile[c0 + k];
+                            const double dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;
+                            const double r2 = fma(dx, dx, fma(dy, dy, dz * dz));
+                            if (r2 < pp.a2) pair_term<P, UNW>(dx, dy, dz, r2, pj.w, pp, u, fwx, fwy, fwz, fux, fuy, fuz);
+                        }
+                    }
+                }
+            }
+        }
+        if (active) {
+            store_acc(acc, orig, pp.convention, pi.w, fwx, fwy, fwz, fux, fuy, fuz);
+            esum += 0.5 * pi.w * u;
+        }
+    }
+    for (int ii = imain; ii < i1; ii++) { // overflow particles: lane = candidate
+        const int orig = order[ii];
+        if (orig >= pp.n_owned) continue;
+        const double4 pi = ps[ii];
+        double u = 0, fwx = 0, fwy = 0, fwz = 0, fux = 0, fuy = 0, fuz = 0;
+        for (int row = 0; row < 9; row++) {
+            RowSeg seg[3];
+            const int nseg = row_segments(pp, cstart, cx, cy, cz, row, seg);
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                if (s >= nseg) break;
+                const double xi = pi.x - seg[s].sx, yi = pi.y - seg[s].sy, zi = pi.z - seg[s].sz;
+                for (int j = seg[s].j0 + tid; j < seg[s].j1; j += PAIR4_THREADS) {
+                    const double4 pj = ps[j];
+                    const double dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;
+                    const double r2 = fma(dx, dx, fma(dy, dy, dz * dz));
+                    if (r2 < pp.a2 && j != ii) pair_term<P, UNW>(dx, dy, dz, r2, pj.w, pp, u, fwx, fwy, fwz, fux, fuy, fuz);
+                }
+            }
+        }
+        u = wave_sum(u); fwx = wave_sum(fwx); fwy = wave_sum(fwy); fwz = wave_sum(fwz);
+        if (UNW) { fux = wave_sum(fux); fuy = wave_sum(fuy); fuz = wave_sum(fuz); }
+        if (tid == 0) {
+            store_acc(acc, orig, pp.convention, pi.w, fwx, fwy, fwz, fux, fuy, fuz);
+            esum += 0.5 * pi.w * u;
+        }
+    }
+    esum = wave_sum(esum);
+    if (tid == 0) epart[cell] = esum;
+}
+
 void launch_pair_cells(hipStream_t st, const double4 *ps, const int *cstart, const int *order, int ncell,
                        const PairParams &pp, double *acc, double *epart, int variant) {
     const bool unw = pp.convention == MSM_AMD_ACC_LITERAL;
@@ -378,7 +623,9 @@ void launch_pair_cells(hipStream_t st, const double4 *ps, const int *cstart, con
             else hipLaunchKernelGGL((KERN<6, false>), dim3(ncell), dim3(NT), 0, st, ps, cstart, order, pp, acc, epart);  \
         }                                                                                                              \
     } while (0)
-    if (variant == 2) LAUNCH_PAIR(k_pair_cells2, PAIR2_THREADS);
+    if (variant == 4) LAUNCH_PAIR(k_pair_cells4, PAIR4_THREADS);
+    else if (variant == 3) LAUNCH_PAIR(k_pair_cells3, PAIR3_THREADS);
+    else if (variant == 2) LAUNCH_PAIR(k_pair_cells2, PAIR2_THREADS);
     else LAUNCH_PAIR(k_pair_cells, PAIR_THREADS);
 #undef LAUNCH_PAIR
 }
@@ -689,6 +936,40 @@ void launch_conv_direct(hipStream_t st, const double *q, const double *K, const 
     c.z0 = z0; c.nz = nz; c.accumulate = accumulate;
     const size_t n = (size_t)M[0] * M[1] * nz;
     hipLaunchKernelGGL(k_conv_direct, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, q, K, e, c);
+}
+
+// Small grids (the coarsest levels and the Fourier top level, a few thousand nodes with a stencil that spans
+// the whole period): one wave per output node, lanes stride over the taps, butterfly reduction.  A thread per
+// node would leave almost the whole chip idle and serialise thousands of dependent loads.
+__global__ __launch_bounds__(256) void k_conv_small(const double *__restrict__ q, const double *__restrict__ K,
+                                                    double *__restrict__ e, ConvArgs c) {
+    const int Mx = c.M[0], My = c.M[1], Mz = c.M[2];
+    const int nout = Mx * My * c.nz;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= nout) return;
+    const int mx = w % Mx, my = (w / Mx) % My, mz = c.z0 + w / (Mx * My);
+    const int T = c.ks[0] * c.ks[1] * c.ks[2];
+    double s = 0.0;
+    for (int t = lane; t < T; t += 64) {
+        const int sx = t % c.ks[0], sy = (t / c.ks[0]) % c.ks[1], sz = t / (c.ks[0] * c.ks[1]);
+        const int nx = modp(mx - (c.kf[0] + sx), Mx), ny = modp(my - (c.kf[1] + sy), My), nz = modp(mz - (c.kf[2] + sz), Mz);
+        s = fma(K[t], q[((size_t)nz * My + ny) * Mx + nx], s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) {
+        const size_t o = ((size_t)mz * My + my) * Mx + mx;
+        e[o] = c.accumulate ? e[o] + s : s;
+    }
+}
+
+void launch_conv_small(hipStream_t st, const double *q, const double *K, const int M[3], const int ksize[3],
+                       const int kfirst[3], double *e, int z0, int nz, int accumulate) {
+    ConvArgs c;
+    for (int d = 0; d < 3; d++) { c.M[d] = M[d]; c.ks[d] = ksize[d]; c.kf[d] = kfirst[d]; }
+    c.z0 = z0; c.nz = nz; c.accumulate = accumulate;
+    const int nout = M[0] * M[1] * nz;
+    hipLaunchKernelGGL(k_conv_small, dim3((nout + 3) / 4), dim3(256), 0, st, q, K, e, c);
 }
 
 // LDS-tiled convolution.  A workgroup owns TX x TY x TZ outputs and stages the

@@ -65,6 +65,9 @@ void launch_prolong_axis(hipStream_t st, const double *in, double *out, const in
 // ---- grid convolution: e[m] = sum_s K[s] q[(m - (first + s)) mod M] for planes [z0, z0+nz) ----
 void launch_conv_direct(hipStream_t st, const double *q, const double *K, const int M[3], const int ksize[3],
                         const int kfirst[3], double *e, int z0, int nz, int accumulate);
+// one wave per output node (small grids with stencils spanning the period)
+void launch_conv_small(hipStream_t st, const double *q, const double *K, const int M[3], const int ksize[3],
+                       const int kfirst[3], double *e, int z0, int nz, int accumulate);
 // LDS-tiled variant; returns false if the stencil shape is not covered (caller falls back to direct)
 bool launch_conv_tiled(hipStream_t st, const double *q, const double *K, const int M[3], const int ksize[3],
                        const int kfirst[3], double *e, int z0, int nz);

@@ -1,0 +1,162 @@
+"""CPU-side checks of the product library: it loads, exports every symbol the header declares, keeps the
+reference's msm_stats layout, restates the host helpers exactly, builds the same stencils as the oracle, and
+refuses to compute without a GPU (no fallback).  No device work is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def msm():
+    import msm_amd
+    msm_amd.load()
+    return msm_amd
+
+
+def test_library_exports_every_declared_symbol(msm):
+    hdr = open(os.path.join(ROOT, "include", "msm_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(msm_amd_\w+|msmperiodic|msmPeriodicRunner|mylog2|choose\w+|minOf3Integers|data_read|"
+                           r"short_range_periodic|print_stats|msm4g_linkedlist_\w+)\s*\(", hdr))
+    names -= {"msm_amd_plan_desc", "msm_amd_handle", "msm_amd_hostplan"}
+    assert len(names) >= 55
+    lib = C.CDLL(msm.capi.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+    # and the Python binding covers the same set
+    assert set(msm.capi.SIGNATURES) == names, set(msm.capi.SIGNATURES) ^ names
+
+
+def test_msm_stats_layout(msm):
+    S = msm.capi.MsmStats
+    assert C.sizeof(S) == 960
+    # offsets of the reference's struct (msm/msmLibrary.h:46-110), measured against the real header
+    want = {"N": 0, "h": 16, "beta": 72, "csr": 96, "chinx": 104, "cvecx": 120, "clenx": 144, "chisum": 160, "chi": 168,
+            "sLsize": 176, "M0": 192, "Mx": 204, "Mlx": 240, "slsizex": 360, "Ax": 480, "size": 492, "rminx": 616,
+            "volume": 664, "short_range_interactions": 680, "netcharge": 696, "netgridcharge": 704,
+            "cputime_initialization": 784, "cputime_total": 880, "potential_total": 888, "potential_long_fourier": 952}
+    for k, off in want.items():
+        assert getattr(S, k).offset == off, (k, getattr(S, k).offset, off)
+
+
+def test_helpers_bit_exact(msm):
+    lib = msm.load()
+    h = O.golden("helpers.json")
+    for row in h["rows"]:
+        M = lib.chooseM(row["htilde"], row["A"])
+        assert M == row["M"]
+        hx, a, L = row["A"] / M, row["abar"] * row["htilde"], row["L"]
+        b = lib.choosebetaNew(1e-12, (2.0 ** L) * a, (2.0 ** (L - 1)) * hx)
+        assert b == row["beta"]
+        assert lib.choosekmax(1e-12, b, (2.0 ** (L - 1)) * hx) == row["kmax_double"]
+        assert lib.chooseL(M, M, M, row["N"]) == 1   # msmLibrary.c:64-66
+    for x, y in h["extra"]["mylog2"]:
+        assert lib.mylog2(x) == y
+    for a, b, c, m in h["extra"]["minOf3Integers"]:
+        assert lib.minOf3Integers(a, b, c) == m
+
+
+def test_short_range_periodic_host(msm):
+    lib = msm.load()
+    fx = O.golden("msmPeriodic_changaN8.json")
+    r = np.array(fx["system"]["r"]) + 0.5
+    q = np.array(fx["system"]["q"])
+    f1, f2 = np.zeros(24), np.zeros(24)
+    dp = O._dp
+    for i in range(8):
+        for j in range(8):
+            u1 = lib.short_range_periodic(i, j, r.ctypes.data_as(dp), q.ctypes.data_as(dp), 3, 2.0,
+                                          f1.ctypes.data_as(dp), 1.0, 1.0, 1.0)
+            u2 = O.lib().or_short_range_periodic(i, j, r.ctypes.data_as(dp), q.ctypes.data_as(dp), 3, 2.0,
+                                                 f2.ctypes.data_as(dp), 1.0, 1.0, 1.0)
+            assert u1 == u2
+    np.testing.assert_allclose(f1, f2, rtol=1e-14, atol=1e-20)
+
+
+def test_linked_list_and_data_read(msm, tmp_path):
+    lib = msm.load()
+    ll = lib.msm4g_linkedlist_new()
+    for k in (5, 7, 9):
+        lib.msm4g_linkedlist_addvalue(ll, k, k * 1.5)
+    lib.msm4g_linkedlist_add(ll, 11)
+    assert lib.msm4g_linkedlist_search(ll, 9) == 2 and lib.msm4g_linkedlist_search(ll, 4) == -1
+    assert lib.msm4g_linkedlist_getvalue(ll, 1) == 10.5 and lib.msm4g_linkedlist_getvalue(ll, 9) == -1
+    lib.msm4g_linkedlist_destroy(ll)
+    p = tmp_path / "sys.txt"
+    p.write_text("2.0 3.0 4.0\n2\n 0.1 0.2 0.3 1.0\n 0.4 0.5 0.6 -1.0\n")
+    q, r = O._dp(), O._dp()
+    n = C.c_int()
+    L = [C.c_double() for _ in range(3)]
+    assert lib.data_read(str(p).encode(), C.byref(q), C.byref(r), C.byref(n), *[C.byref(x) for x in L]) == 0
+    assert n.value == 2 and [x.value for x in L] == [2.0, 3.0, 4.0]
+    assert [r[i] for i in range(6)] == [0.1, 0.2, 0.3, 0.4, 0.5, 0.6] and [q[0], q[1]] == [1.0, -1.0]
+    assert lib.data_read(b"/nonexistent/file", C.byref(q), C.byref(r), C.byref(n), *[C.byref(x) for x in L]) == 1
+
+
+@pytest.mark.parametrize("N,L,p,mu", [(512, 1, 4, 10), (4096, 2, 4, 10), (4096, 2, 6, 6), (64, 1, 4, 10), (30000, 3, 4, 10)])
+def test_host_plan_matches_oracle(msm, N, L, p, mu):
+    """omega', J, every level stencil and the Fourier stencil: the product's separable construction against the
+    oracle's direct sums."""
+    A = (1.0, 1.0, 1.0)
+    d = msm.plan_auto(N, A, p, mu, 4.0, L)
+    hp = msm.HostPlan(d)
+    sp = O.SpecPlan.auto(N, A, p, mu, 4.0, L, nthreads=4)
+    assert (d.beta, d.kmax, d.a, list(d.M)) == (sp.prm.beta, sp.prm.kmax, sp.prm.a, list(sp.prm.M))
+    assert np.array_equal(hp.wprime(), O.wprime(p, mu))
+    tol = 2e-11 if p == 6 else 1e-12
+    for l in range(L):
+        K, f = hp.stencil(l)
+        Ko, fo = sp.stencil(l)
+        assert f == fo and K.shape == Ko.shape
+        assert np.abs(K - Ko).max() <= tol * np.abs(Ko).max()
+    K, _ = hp.stencil(L)
+    Ko = sp.stencil_top()
+    assert np.abs(K - Ko).max() <= 1e-12 * np.abs(Ko).max()
+    J = np.zeros(4)
+    O.lib().or_jcoef(p, J.ctypes.data_as(O._dp))
+    assert np.array_equal(hp.scalars()["J"], J)
+    assert hp.scalars()["gamma0"] == O.lib().or_gamma(0.0, p)
+
+
+def test_literal_host_plan_matches_reference_stencil(msm):
+    """Literal mode's level-0 stencil against the reference's own `Stencil[0]` dump (printed with %25.16f)."""
+    for name in ("changaN8", "CsClN16", "changaN64", "changaN512"):
+        fx = O.golden("msmPeriodic_%s.json" % name)
+        s = fx["system"]
+        d = msm.plan_auto(s["N"], s["L"], 4, 10, 4.0, 1)
+        hp = msm.HostPlan(d, literal=True)
+        K, first = hp.stencil(0)
+        ref = np.array(fx["stencil0"])
+        assert K.size == ref.size
+        assert np.abs(K.ravel() - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+def test_plan_auto_levels(msm):
+    d = msm.plan_auto(1000000, (1.0, 1.0, 1.0), 4, 10, 4.0, 0)
+    assert list(d.M) == [96, 96, 96] and d.L == 4          # 96 -> 48 -> 24 -> 12
+    d = msm.plan_auto(100000, (1.0, 1.0, 1.0), 4, 10, 4.0, 0)
+    assert list(d.M) == [48, 48, 48] and d.L == 3          # 48 -> 24 -> 12
+    with pytest.raises(msm.MsmAmdError):
+        msm.plan_auto(1000, (1.0, 1.0, 1.0), 4, 10, 4.0, 6)   # 16 is not divisible by 32
+    with pytest.raises(msm.MsmAmdError):
+        msm.HostPlan(msm.plan_explicit(10, (1, 1, 1), (8, 8, 8), 5, 10, 1, 0.3, 3.0, 5))
+
+
+def test_no_cpu_fallback(msm):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    d = msm.plan_auto(100, (1.0, 1.0, 1.0), 4, 10, 4.0, 1)
+    h = C.c_void_p()
+    rc = msm.load().msm_amd_create(C.byref(d), 0, None, C.byref(h))
+    assert rc == -2 and not h.value   # MSM_AMD_ENODEV
+    assert b"no CPU path" in msm.load().msm_amd_last_error()
+    with pytest.raises(msm.MsmAmdError):
+        msm.Engine(d)

@@ -108,11 +108,14 @@ def test_stagewise_parity(msm, torch, N, A, p, mu, L):
         qg = torch.as_tensor(grids_q[l], device=dev)
         e = torch.zeros_like(qg)
         eo = sp.convolve(l, grids_q[l])
-        for tiled in (0, 1):
+        for tiled, small in ((0, 0), (1, 0), (0, 1)):   # thread-per-node, LDS-tiled, wave-per-node
             eng.set_option("conv_tiled", tiled)
+            eng.set_option("conv_small", small)
             e.zero_()
             eng.op_convolve(l, qg, e)
-            assert grid_err(e.cpu().numpy(), eo) < TOL, ("level", l, "tiled", tiled)
+            assert grid_err(e.cpu().numpy(), eo) < TOL, ("level", l, "tiled", tiled, "small", small)
+        eng.set_option("conv_tiled", 1)
+        eng.set_option("conv_small", 1)
     qg = torch.as_tensor(grids_q[L - 1], device=dev)
     e = torch.zeros_like(qg)
     eng.op_convolve(L, qg, e)
@@ -155,19 +158,21 @@ def test_pair_kernel_variants_agree(msm, torch):
     eng = msm.Engine(desc)
     rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
     out = []
-    for v in (1, 2):
+    for v in (1, 2, 3, 4):
         eng.set_option("pair_variant", v)
         en, acc = eng.eval(rd, qd)
         out.append((en.copy(), acc.cpu().numpy().copy()))
-    assert rel_rms(out[1][1], out[0][1]) < 1e-13
-    assert abs(out[1][0][0] - out[0][0][0]) < 1e-13 * abs(out[0][0][0])
+    for k in (1, 2, 3):
+        assert rel_rms(out[k][1], out[0][1]) < 1e-13
+        assert abs(out[k][0][0] - out[0][0][0]) < 1e-13 * abs(out[0][0][0])
     sp = spec_for(desc)
     aw, au, ureal = sp.pairs(r, q)
-    eng.set_option("pair_variant", 2)
-    eng.stage_bin(rd, qd)
-    a2 = torch.zeros((N, 3), dtype=torch.float64, device="cuda:0")
-    eng.stage_pairs(a2)
-    assert rel_rms(a2.cpu().numpy(), aw) < TOL
+    for v in (2, 3, 4):
+        eng.set_option("pair_variant", v)
+        eng.stage_bin(rd, qd)
+        a2 = torch.zeros((N, 3), dtype=torch.float64, device="cuda:0")
+        eng.stage_pairs(a2)
+        assert rel_rms(a2.cpu().numpy(), aw) < TOL
 
 
 def test_conventions(msm, torch):
@@ -296,7 +301,7 @@ def test_edge_cases(msm, torch):
     eng = msm.Engine(d)
     sp = spec_for(d)
     ref = sp.eval(r, q)
-    for v in (1, 2):
+    for v in (1, 2, 3, 4):
         eng.set_option("pair_variant", v)
         en, acc = eng.eval(r, q)
         assert np.abs(en - ref["energies"]).max() < TOL * np.abs(ref["energies"][:6]).max()
@@ -334,10 +339,11 @@ def test_full_size_properties(msm, torch):
     # bitwise reproducible
     en2, acc2 = eng.eval(rd, qd)
     assert np.array_equal(en, en2) and np.array_equal(acc, acc2.cpu().numpy())
-    # both pair kernels agree at full size
-    eng.set_option("pair_variant", 2)
-    en3, acc3 = eng.eval(rd, qd)
-    assert rel_rms(acc3.cpu().numpy(), acc) < 1e-13
+    # the pair kernel variants agree at full size
+    for v in (1, 2, 3, 4):
+        eng.set_option("pair_variant", v)
+        en3, acc3 = eng.eval(rd, qd)
+        assert rel_rms(acc3.cpu().numpy(), acc) < 1e-13
     # invariance under a lattice translation of some particles and under relabelling
     r2 = r.copy()
     r2[::7] += np.array([1.0, -2.0, 3.0])
