@@ -1,0 +1,445 @@
+// Short-range pair sum over cluster pairs (gfx950).
+//
+// The cell-list kernel makes every lane walk every particle of the 27 neighbouring cells, and only one
+// candidate in six lies inside the cutoff.  Here the particles are sorted into (x, y) columns and by z inside
+// a column, and cut into clusters of CL_G = 8 consecutive particles, which are roughly cubic.  A wave owns
+// one cluster i and visits only the clusters j whose bounding box comes within the cutoff of i's box; its 64
+// lanes are the 8 x 8 particle pairs (i, j) of one cluster pair, so every lane does the same branch-free
+// arithmetic, the j particles come straight from L1/L2 (256 contiguous bytes per cluster pair) and each lane
+// keeps a private partial sum that is reduced over j once at the end.  The summation order is fixed by the
+// sort, so results are the same on every run.  Same mathematics as msmLibrary.c:125-182.
+#include "msm_kernels.hpp"
+#include "msm_device.hpp"
+
+#include "msm_amd.h"
+
+namespace msm {
+
+#define CL_NOSHIFT 13          // code (px+1) + 3 (py+1) + 9 (pz+1) of the zero image shift
+#define CL_DUMMY 0x7fffffff
+#define CL_CODE_SHIFT 27
+#define CL_JMASK ((1 << CL_CODE_SHIFT) - 1)
+
+// ---------------------------------------------------------------------------
+// sort into columns / fine z bins, cut into clusters, bounding boxes
+// ---------------------------------------------------------------------------
+__global__ void k_cl_count(const double *__restrict__ r, int N, ClusterGeom g, int *__restrict__ bin_of, int *__restrict__ count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double s[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        double t = r[3 * (size_t)i + d] * g.invA[d];
+        s[d] = t - floor(t);
+    }
+    const int cx = min((int)(s[0] * g.ncx), g.ncx - 1), cy = min((int)(s[1] * g.ncy), g.ncy - 1);
+    const int zf = min((int)(s[2] * g.nzf), g.nzf - 1);
+    const int b = (cy * g.ncx + cx) * g.nzf + zf;
+    bin_of[i] = b;
+    atomicAdd(&count[b], 1);
+}
+
+__global__ void k_cl_colcount(const int *__restrict__ start, ClusterGeom g, int *__restrict__ colncl) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= g.ncols) return;
+    const int n = start[(col + 1) * g.nzf] - start[col * g.nzf];
+    colncl[col] = (n + CL_G - 1) / CL_G;
+}
+
+// Slot of a particle: its column's first slot + its rank inside the column (fine bins in z order, original
+// index inside a fine bin, so the layout does not depend on the order the atomics of the scatter arrived in).
+__global__ void k_cl_finalize(const double *__restrict__ r, const double *__restrict__ q, int N, ClusterGeom g,
+                              const int *__restrict__ bin_of, const int *__restrict__ start, const int *__restrict__ clstart,
+                              const int *__restrict__ slot_idx, int *__restrict__ order, double4 *__restrict__ ps) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const int i = slot_idx[s];
+    const int b = bin_of[i];
+    const int st = start[b], en = start[b + 1];
+    int rank = 0;
+    for (int t = st; t < en; t++) rank += (slot_idx[t] < i);
+    const int col = b / g.nzf;
+    const int dst = CL_G * clstart[col] + (st - start[col * g.nzf]) + rank;
+    double f[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        double t = r[3 * (size_t)i + d] * g.invA[d];
+        f[d] = (t - floor(t)) * g.A[d];
+    }
+    order[dst] = i;
+    ps[dst] = make_double4(f[0], f[1], f[2], q[i]);
+}
+
+// One thread per cluster: pad the tail of a column's last cluster with inert slots and box the real members.
+__global__ void k_cl_bbox(ClusterGeom g, ClusterBuffers b) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ncl = b.clstart[g.ncols];
+    if (k >= ncl) return;
+    int lo = 0, hi = g.ncols; // column with clstart[col] <= k < clstart[col+1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (b.clstart[mid] <= k) lo = mid; else hi = mid;
+    }
+    const int col = lo;
+    const int ncolp = b.start[(col + 1) * g.nzf] - b.start[col * g.nzf];
+    const int nin = min(CL_G, ncolp - CL_G * (k - b.clstart[col]));
+    double4 *p = b.ps + (size_t)CL_G * k;
+    double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+    for (int m = 0; m < nin; m++) {
+        const double4 v = p[m];
+        l[0] = fmin(l[0], v.x); h[0] = fmax(h[0], v.x);
+        l[1] = fmin(l[1], v.y); h[1] = fmax(h[1], v.y);
+        l[2] = fmin(l[2], v.z); h[2] = fmax(h[2], v.z);
+    }
+    for (int m = nin; m < CL_G; m++) {
+        p[m] = make_double4(g.far, g.far, g.far, 0.0);
+        b.order[(size_t)CL_G * k + m] = CL_DUMMY;
+    }
+    b.blo[k] = make_double4(l[0], l[1], l[2], 0.0);
+    b.bhi[k] = make_double4(h[0], h[1], h[2], 0.0);
+}
+
+void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, int N, const ClusterGeom &g,
+                         const ClusterBuffers &b, int *bin_of, int *slot_idx, int *scan_tmp) {
+    hipMemsetAsync(b.count, 0, sizeof(int) * (size_t)g.nbins, st);
+    hipMemsetAsync(b.fill, 0, sizeof(int) * (size_t)g.nbins, st);
+    const int tb = 256, gb = (N + tb - 1) / tb;
+    hipLaunchKernelGGL(k_cl_count, dim3(gb), dim3(tb), 0, st, d_r, N, g, bin_of, b.count);
+    launch_exclusive_scan(st, b.count, g.nbins, scan_tmp, b.start);
+    hipLaunchKernelGGL(k_cl_colcount, dim3((g.ncols + tb - 1) / tb), dim3(tb), 0, st, b.start, g, b.colncl);
+    launch_exclusive_scan(st, b.colncl, g.ncols, scan_tmp, b.clstart);
+    launch_bin_scatter(st, bin_of, N, b.start, b.fill, slot_idx);
+    hipLaunchKernelGGL(k_cl_finalize, dim3(gb), dim3(tb), 0, st, d_r, d_q, N, g, bin_of, b.start, b.clstart, slot_idx, b.order,
+                       b.ps);
+    hipLaunchKernelGGL(k_cl_bbox, dim3((g.max_clusters + tb - 1) / tb), dim3(tb), 0, st, g, b);
+}
+
+// ---------------------------------------------------------------------------
+// candidate enumeration: every (cluster j, image shift) whose box comes within a of cluster i's box
+// ---------------------------------------------------------------------------
+struct IBox {
+    double lox, loy, loz, hix, hiy, hiz;
+};
+
+// a lane's walk over one column of the extended (unwrapped) column grid
+struct ColCursor {
+    int col;      // wrapped column index
+    int sxy;      // (px+1) + 3 (py+1): periods the column was wrapped by
+    double sx, sy;
+    int zf0, zf1; // extended fine-bin range to visit
+    int k;        // current z period (-1, 0, 1); -2 before the first segment
+    int cur, end; // clusters [cur, end] of the current segment
+};
+
+__device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+__device__ __forceinline__ bool cl_column(const ClusterGeom &g, double a2, const IBox &ib, int ex0, int ey0, int nex, int cc,
+                                          ColCursor &c) {
+    const double eps = 1e-6; // slack, in bins, for the different roundings of the sort and of this walk
+    const int exi = ex0 + cc % nex, eyi = ey0 + cc / nex;
+    const double gx = fmax(0.0, fmax(ib.lox - (exi + 1 + eps) * g.pitch[0], (exi - eps) * g.pitch[0] - ib.hix));
+    const double gy = fmax(0.0, fmax(ib.loy - (eyi + 1 + eps) * g.pitch[1], (eyi - eps) * g.pitch[1] - ib.hiy));
+    const double rem = a2 - gx * gx - gy * gy;
+    if (rem <= 0.0) return false;
+    const double az = sqrt(rem);
+    const int px = floor_div(exi, g.ncx), py = floor_div(eyi, g.ncy);
+    if (px < -1 || px > 1 || py < -1 || py > 1) return false; // cannot happen while the cell is >= 3 cutoffs wide
+    c.col = (eyi - py * g.ncy) * g.ncx + (exi - px * g.ncx);
+    c.sxy = (px + 1) + 3 * (py + 1);
+    c.sx = px * g.A[0];
+    c.sy = py * g.A[1];
+    c.zf0 = (int)floor((ib.loz - az) * g.inv_dzf - eps);
+    c.zf1 = (int)floor((ib.hiz + az) * g.inv_dzf + eps);
+    c.k = -2;
+    c.cur = 1;
+    c.end = 0;
+    return true;
+}
+
+__device__ __forceinline__ bool cl_next_segment(const ClusterGeom &g, const int *__restrict__ start,
+                                                const int *__restrict__ clstart, ColCursor &c) {
+    while (c.k < 1) {
+        c.k = c.k < -1 ? -1 : c.k + 1;
+        const int off = c.k * g.nzf;
+        const int lo = max(c.zf0, off) - off, hi = min(c.zf1, off + g.nzf - 1) - off;
+        if (lo > hi) continue;
+        const int base = c.col * g.nzf;
+        const int colp0 = start[base], p0 = start[base + lo], p1 = start[base + hi + 1];
+        if (p1 <= p0) continue;
+        const int c0 = clstart[c.col];
+        c.cur = c0 + (p0 - colp0) / CL_G;
+        c.end = c0 + (p1 - 1 - colp0) / CL_G;
+        return true;
+    }
+    return false;
+}
+
+// Calls emit(keep, jcl, code) with all 64 lanes converged; each lane brings its own candidate.
+template <class Emit>
+__device__ __forceinline__ void cl_enumerate(const ClusterGeom &g, const ClusterBuffers &b, double a, double a2, const IBox &ib,
+                                             int lane, Emit &&emit) {
+    const double eps = 1e-6;
+    const int ex0 = (int)floor((ib.lox - a) * g.inv_pitch[0] - eps), ex1 = (int)floor((ib.hix + a) * g.inv_pitch[0] + eps);
+    const int ey0 = (int)floor((ib.loy - a) * g.inv_pitch[1] - eps), ey1 = (int)floor((ib.hiy + a) * g.inv_pitch[1] + eps);
+    const int nex = ex1 - ex0 + 1, ntot = nex * (ey1 - ey0 + 1);
+    for (int base = 0; base < ntot; base += 64) {
+        ColCursor c;
+        bool live = false;
+        if (base + lane < ntot && cl_column(g, a2, ib, ex0, ey0, nex, base + lane, c)) live = cl_next_segment(g, b.start, b.clstart, c);
+        while (__ballot(live)) {
+            int jcl = 0, code = CL_NOSHIFT;
+            bool keep = false;
+            if (live) {
+                jcl = c.cur;
+                code = c.sxy + 9 * (c.k + 1);
+                const double sz = c.k * g.A[2];
+                const double4 jl = b.blo[jcl], jh = b.bhi[jcl];
+                const double gx = fmax(0.0, fmax(jl.x + c.sx - ib.hix, ib.lox - (jh.x + c.sx)));
+                const double gy = fmax(0.0, fmax(jl.y + c.sy - ib.hiy, ib.loy - (jh.y + c.sy)));
+                const double gz = fmax(0.0, fmax(jl.z + sz - ib.hiz, ib.loz - (jh.z + sz)));
+                keep = gx * gx + gy * gy + gz * gz < a2;
+            }
+            emit(keep, jcl, code);
+            if (live && ++c.cur > c.end) live = cl_next_segment(g, b.start, b.clstart, c);
+        }
+    }
+}
+
+__device__ __forceinline__ int lane_rank(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+}
+
+// One wave per cluster: the list of its neighbour clusters.  Entry 0 is the cluster itself; unshifted
+// neighbours follow from the front, neighbours seen through a periodic image are stored from the back with
+// their shift code in the top bits.
+__global__ __launch_bounds__(256) void k_cl_list(ClusterGeom g, ClusterBuffers b, double a, double a2) {
+    const int lane = threadIdx.x & 63;
+    const int icl = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int ncl = b.clstart[g.ncols];
+    if (icl >= ncl) return;
+    const double4 il = b.blo[icl], ih = b.bhi[icl];
+    const IBox ib = {il.x, il.y, il.z, ih.x, ih.y, ih.z};
+    const int S = g.list_stride;
+    int *__restrict__ L = b.list + (size_t)icl * S;
+    int n0 = 1, n1 = 0;
+    bool overflow = false;
+    if (lane == 0) L[0] = icl;
+    cl_enumerate(g, b, a, a2, ib, lane, [&](bool keep, int jcl, int code) {
+        if (jcl == icl && code == CL_NOSHIFT) keep = false;
+        const bool k0 = keep && code == CL_NOSHIFT, k1 = keep && code != CL_NOSHIFT;
+        const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+        const int c0 = __popcll(m0), c1 = __popcll(m1);
+        if (n0 + n1 + c0 + c1 > S) overflow = true;
+        else {
+            if (k0) L[n0 + lane_rank(m0)] = jcl;
+            if (k1) L[S - 1 - (n1 + lane_rank(m1))] = (int)((unsigned)jcl | ((unsigned)code << CL_CODE_SHIFT));
+        }
+        n0 += c0;
+        n1 += c1;
+    });
+    if (lane == 0) {
+        b.n0[icl] = overflow ? -1 : n0;
+        b.n1[icl] = n1;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// pair arithmetic
+// ---------------------------------------------------------------------------
+// 1/sqrt(x) to double precision: single-precision hardware seed (relative error < 2^-21 after the
+// conversions) and one third-order correction, error ~ (5/16) e^3.
+__device__ __forceinline__ double rsqrt_seeded(double x) {
+    const double y0 = (double)__builtin_amdgcn_rsqf((float)x);
+    const double e = fma(-x * y0, y0, 1.0);
+    return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
+
+// One (i, j) pair, branch-free: a pair outside the cutoff runs the same arithmetic with its charge set to 0.
+// g0(r) = 1/r - gamma(r/a)/a,  g0'(r)/r = -1/r^3 + D(y)/a^3  (msmLibrary.h:18-19 for p = 4).
+template <int P, bool SELF, bool SKIP = false>
+__device__ __forceinline__ void cl_slot(double xi, double yi, double zi, const double4 &pj, const PairParams &pp, bool other,
+                                        double &u, double &fx, double &fy, double &fz) {
+    const double dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;
+    double r2 = fma(dx, dx, fma(dy, dy, dz * dz));
+    bool in = r2 < pp.a2;
+    if (SELF) {
+        in = in && other;
+        r2 = in ? r2 : pp.a2;
+    }
+    if (SKIP && !__ballot(in)) return; // no pair of this cluster pair is inside the cutoff
+    const double qm = in ? pj.w : 0.0;
+    const double ir = rsqrt_seeded(r2);
+    const double y = fma(r2, pp.inv_a2, -1.0);
+    double gam = pp.cga[P - 1], dg = pp.cda[P - 2];
+#pragma unroll
+    for (int k = P - 2; k >= 0; k--) gam = fma(gam, y, pp.cga[k]);
+#pragma unroll
+    for (int k = P - 3; k >= 0; k--) dg = fma(dg, y, pp.cda[k]);
+    const double g0 = ir - gam;
+    const double s = fma(-(ir * ir), ir, dg);
+    u = fma(qm, g0, u);
+    const double qs = qm * s;
+    fx = fma(qs, dx, fx);
+    fy = fma(qs, dy, fy);
+    fz = fma(qs, dz, fz);
+}
+
+struct LaneI {
+    double x, y, z, q;
+    int orig;
+    bool owned;
+};
+
+__device__ __forceinline__ LaneI load_lane_i(const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, int icl, int ii) {
+    LaneI L;
+    const double4 pi = b.ps[(size_t)CL_G * icl + ii];
+    L.orig = b.order[(size_t)CL_G * icl + ii];
+    L.owned = L.orig < pp.n_owned;
+    // a padding slot as i: move it away from the padding slots it would meet as j (distance 0)
+    const bool dummy = L.orig == CL_DUMMY;
+    L.x = dummy ? -2.0 * g.far : pi.x;
+    L.y = pi.y;
+    L.z = pi.z;
+    L.q = pi.w;
+    return L;
+}
+
+// sum the 8 lanes that share a particle i (consecutive lanes), then write its acceleration and energy share
+__device__ __forceinline__ void cl_finish(const LaneI &I, const PairParams &pp, int jj, int icl, double u, double fx, double fy,
+                                          double fz, double *__restrict__ acc, double *__restrict__ epart, int lane) {
+#pragma unroll
+    for (int off = 1; off < CL_G; off <<= 1) {
+        u += __shfl_xor(u, off);
+        fx += __shfl_xor(fx, off);
+        fy += __shfl_xor(fy, off);
+        fz += __shfl_xor(fz, off);
+    }
+    double e = 0.0;
+    if (jj == 0 && I.owned) {
+        const double w = pp.convention == MSM_AMD_ACC_FORCE ? -I.q : 1.0;
+        acc[3 * (size_t)I.orig] = w * fx;
+        acc[3 * (size_t)I.orig + 1] = w * fy;
+        acc[3 * (size_t)I.orig + 2] = w * fz;
+        e = 0.5 * I.q * u;
+    }
+    e = wave_sum(e);
+    if (lane == 0) epart[icl] = e;
+}
+
+__device__ __forceinline__ void shift_of_code(const ClusterGeom &g, int code, double &sx, double &sy, double &sz) {
+    sx = (code % 3 - 1) * g.A[0];
+    sy = ((code / 3) % 3 - 1) * g.A[1];
+    sz = (code / 9 - 1) * g.A[2];
+}
+
+// One wave per cluster i, lane = (ii, jj) = (lane / 8, lane % 8); walks the list built by k_cl_list.
+template <int P, bool SKIP>
+__global__ __launch_bounds__(256) void k_pair_clusters(ClusterGeom g, ClusterBuffers b, PairParams pp, double *__restrict__ acc,
+                                                       double *__restrict__ epart) {
+    const int lane = threadIdx.x & 63, ii = lane >> 3, jj = lane & 7;
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int icl = __builtin_amdgcn_readfirstlane(blk * 4 + (threadIdx.x >> 6));
+    if (icl >= g.max_clusters) return;
+    const int ncl = b.clstart[g.ncols];
+    if (icl >= ncl) {
+        if (lane == 0) epart[icl] = 0.0;
+        return;
+    }
+    const int n0 = b.n0[icl], n1 = b.n1[icl];
+    if (n0 < 0) return; // list overflow: left to the direct kernel
+    const LaneI I = load_lane_i(g, b, pp, icl, ii);
+    if (!__ballot(I.owned)) {
+        if (lane == 0) epart[icl] = 0.0;
+        return;
+    }
+    const int S = g.list_stride;
+    const int *__restrict__ L = b.list + (size_t)icl * S;
+    const double4 *__restrict__ pj = b.ps + jj;
+    double u = 0, fx = 0, fy = 0, fz = 0;
+    cl_slot<P, true>(I.x, I.y, I.z, pj[(size_t)CL_G * icl], pp, ii != jj, u, fx, fy, fz);
+    int e = 1;
+    for (; e + 4 <= n0; e += 4) {
+        const int j0 = L[e], j1 = L[e + 1], j2 = L[e + 2], j3 = L[e + 3];
+        const double4 q0 = pj[(size_t)CL_G * j0], q1 = pj[(size_t)CL_G * j1], q2 = pj[(size_t)CL_G * j2], q3 = pj[(size_t)CL_G * j3];
+        cl_slot<P, false, SKIP>(I.x, I.y, I.z, q0, pp, true, u, fx, fy, fz);
+        cl_slot<P, false, SKIP>(I.x, I.y, I.z, q1, pp, true, u, fx, fy, fz);
+        cl_slot<P, false, SKIP>(I.x, I.y, I.z, q2, pp, true, u, fx, fy, fz);
+        cl_slot<P, false, SKIP>(I.x, I.y, I.z, q3, pp, true, u, fx, fy, fz);
+    }
+    for (; e < n0; e++) cl_slot<P, false, SKIP>(I.x, I.y, I.z, pj[(size_t)CL_G * L[e]], pp, true, u, fx, fy, fz);
+    for (e = 0; e < n1; e++) {
+        const int ent = L[S - 1 - e];
+        double sx, sy, sz;
+        shift_of_code(g, (int)((unsigned)ent >> CL_CODE_SHIFT), sx, sy, sz);
+        cl_slot<P, false, SKIP>(I.x - sx, I.y - sy, I.z - sz, pj[(size_t)CL_G * (ent & CL_JMASK)], pp, true, u, fx, fy, fz);
+    }
+    cl_finish(I, pp, jj, icl, u, fx, fy, fz, acc, epart, lane);
+}
+
+// The same sum without lists: the wave enumerates its candidates and evaluates each surviving cluster pair on
+// the spot.  With FALLBACK it only takes the clusters whose list did not fit.
+template <int P, bool FALLBACK>
+__global__ __launch_bounds__(256) void k_pair_clusters_direct(ClusterGeom g, ClusterBuffers b, PairParams pp, double a,
+                                                              double *__restrict__ acc, double *__restrict__ epart) {
+    const int lane = threadIdx.x & 63, ii = lane >> 3, jj = lane & 7;
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int icl = __builtin_amdgcn_readfirstlane(blk * 4 + (threadIdx.x >> 6));
+    if (icl >= g.max_clusters) return;
+    const int ncl = b.clstart[g.ncols];
+    if (icl >= ncl) {
+        if (!FALLBACK && lane == 0) epart[icl] = 0.0;
+        return;
+    }
+    if (FALLBACK && b.n0[icl] >= 0) return;
+    const LaneI I = load_lane_i(g, b, pp, icl, ii);
+    if (!__ballot(I.owned)) {
+        if (lane == 0) epart[icl] = 0.0;
+        return;
+    }
+    const double4 il = b.blo[icl], ih = b.bhi[icl];
+    const IBox ib = {il.x, il.y, il.z, ih.x, ih.y, ih.z};
+    const double4 *__restrict__ pj = b.ps + jj;
+    double u = 0, fx = 0, fy = 0, fz = 0;
+    cl_enumerate(g, b, a, pp.a2, ib, lane, [&](bool keep, int jcl, int code) {
+        unsigned long long m = __ballot(keep);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int j = __builtin_amdgcn_readlane(jcl, l), cd = __builtin_amdgcn_readlane(code, l);
+            const double4 q = pj[(size_t)CL_G * j];
+            if (cd == CL_NOSHIFT) {
+                if (j == icl) cl_slot<P, true>(I.x, I.y, I.z, q, pp, ii != jj, u, fx, fy, fz);
+                else cl_slot<P, false>(I.x, I.y, I.z, q, pp, true, u, fx, fy, fz);
+            } else {
+                double sx, sy, sz;
+                shift_of_code(g, cd, sx, sy, sz);
+                cl_slot<P, false>(I.x - sx, I.y - sy, I.z - sz, q, pp, true, u, fx, fy, fz);
+            }
+        }
+    });
+    cl_finish(I, pp, jj, icl, u, fx, fy, fz, acc, epart, lane);
+}
+
+void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double *acc,
+                          double *epart, int variant) {
+    const double a = sqrt(pp.a2);
+    const int nblk = (g.max_clusters + 3) / 4;
+    if (variant == 1) {
+        if (pp.p == 4) hipLaunchKernelGGL((k_pair_clusters_direct<4, false>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart);
+        else hipLaunchKernelGGL((k_pair_clusters_direct<6, false>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart);
+        return;
+    }
+    hipLaunchKernelGGL(k_cl_list, dim3(nblk), dim3(256), 0, st, g, b, a, pp.a2);
+    const bool skip = variant == 2;
+    if (pp.p == 4) {
+        if (skip) hipLaunchKernelGGL((k_pair_clusters<4, true>), dim3(nblk), dim3(256), 0, st, g, b, pp, acc, epart);
+        else hipLaunchKernelGGL((k_pair_clusters<4, false>), dim3(nblk), dim3(256), 0, st, g, b, pp, acc, epart);
+        hipLaunchKernelGGL((k_pair_clusters_direct<4, true>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart);
+    } else {
+        if (skip) hipLaunchKernelGGL((k_pair_clusters<6, true>), dim3(nblk), dim3(256), 0, st, g, b, pp, acc, epart);
+        else hipLaunchKernelGGL((k_pair_clusters<6, false>), dim3(nblk), dim3(256), 0, st, g, b, pp, acc, epart);
+        hipLaunchKernelGGL((k_pair_clusters_direct<6, true>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart);
+    }
+}
+
+} // namespace msm

@@ -1,0 +1,29 @@
+// Small device helpers shared by the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace msm {
+
+// Blocks b and b+8 share an XCD (and its L2).  Give each XCD a contiguous run of
+// logical ids so that neighbouring tiles / cells, which share halo data, meet in one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, k = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+__device__ __forceinline__ int wrap1(int i, int M) { // i in [-M, 2M)
+    i = (i < 0) ? i + M : i;
+    return (i >= M) ? i - M : i;
+}
+__device__ __forceinline__ int modp(int i, int M) {
+    int r = i % M;
+    return r < 0 ? r + M : r;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+} // namespace msm

@@ -47,7 +47,7 @@ struct msm_amd_handle {
     // reductions
     double *epart = nullptr;
     int nepart = 0;
-    double *parts = nullptr; // [grid NPARTS | four NPARTS | charge 2*NPARTS]
+    double *parts = nullptr; // [grid NPARTS | four NPARTS | charge 2*NPARTS | pair NPARTS]
     double *d_energies = nullptr, *h_energies = nullptr;
     const double *cur_r = nullptr, *cur_q = nullptr;
     // host staging for eval_host
@@ -57,7 +57,16 @@ struct msm_amd_handle {
     hipEvent_t ev[T_COUNT + 1];
     bool ev_made = false;
     double last_ms[T_COUNT];
-    int opt_pair_variant = 1, opt_conv_tiled = 1, opt_conv_small = 1;
+    int opt_pair_variant = 5, opt_conv_tiled = 1, opt_conv_small = 1;
+    // cluster-pair path of the short-range sum
+    ClusterGeom clg;
+    ClusterBuffers clb = {};
+    bool cells_binned = false, clusters_sorted = false;
+    // LDS-tiled anterpolation
+    TileGeom tiles = {};
+    double *tile_scratch = nullptr;
+    bool anterp_tiled = false;
+    int opt_anterp_tiled = 1;
 };
 
 static int g_mode = MSM_AMD_MODE_AUTO;
@@ -144,6 +153,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
     pp.inv_a2 = 1.0 / (d.a * d.a);
     pp.inv_a3 = 1.0 / (d.a * d.a * d.a);
     gamma_poly(d.p, pp.cg, pp.cd);
+    for (int k = 0; k < 8; k++) { pp.cga[k] = pp.cg[k] * pp.inv_a; pp.cda[k] = pp.cd[k] * pp.inv_a3; }
     pp.p = d.p;
     pp.convention = d.acc_convention;
     pp.n_owned = h->n_owned;
@@ -158,10 +168,36 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         sp.node_shift[k] = literal ? d.M[k] / 2 - 1 : 0;
         sp.drop_last[k] = (literal && (d.M[k] & 1)) ? 1 : 0;
     }
+    spline_pieces(d.p, sp.piece, sp.dpiece);
     sp.z0 = d.zplane0;
     sp.nz = d.nzplanes;
     sp.convention = d.acc_convention;
     sp.n_owned = h->n_owned;
+
+    // columns of the cluster sort: pitch ~ edge of a cube holding CL_G particles at the mean density of the
+    // occupied part of the cell, fine z bins of an eighth of that
+    ClusterGeom &cg = h->clg;
+    {
+        double occ = 1.0; // fraction of the cell a slab rank's particles (owned + halo) can occupy
+        if (d.nzplanes < d.M[2]) occ = std::min(1.0, (d.nzplanes + 2.0 * (d.a / h->hp.hl[0][2] + d.p / 2)) / d.M[2]);
+        const double vol = d.A[0] * d.A[1] * d.A[2] * occ;
+        const double c = std::cbrt(CL_G * vol / std::max(N, 1));
+        cg.ncx = std::max(1, (int)std::floor(d.A[0] / c + 0.5));
+        cg.ncy = std::max(1, (int)std::floor(d.A[1] / c + 0.5));
+        cg.ncols = cg.ncx * cg.ncy;
+        long nzf = std::max(1L, (long)std::floor(8.0 * d.A[2] / c + 0.5));
+        nzf = std::min(nzf, std::max(1L, (4L * N + 1024) / cg.ncols));
+        cg.nzf = (int)nzf;
+        cg.nbins = cg.ncols * cg.nzf;
+        cg.max_clusters = (N + CL_G - 1) / CL_G + cg.ncols;
+        cg.list_stride = 256;
+        double amax = 0;
+        for (int k = 0; k < 3; k++) { cg.A[k] = d.A[k]; cg.invA[k] = 1.0 / d.A[k]; amax = std::max(amax, d.A[k]); }
+        cg.pitch[0] = d.A[0] / cg.ncx; cg.pitch[1] = d.A[1] / cg.ncy;
+        cg.inv_pitch[0] = cg.ncx / d.A[0]; cg.inv_pitch[1] = cg.ncy / d.A[1];
+        cg.dzf = d.A[2] / cg.nzf; cg.inv_dzf = cg.nzf / d.A[2];
+        cg.far = -1.0e3 * amax;
+    }
 
 #define DA(ptr, n)                      \
     do {                                \
@@ -172,8 +208,17 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
     DA(h->ccount, h->ncell); DA(h->cstart, h->ncell + 1); DA(h->cfill, h->ncell);
     DA(h->gcount, h->gridg.nbins); DA(h->gstart, h->gridg.nbins + 1); DA(h->gfill, h->gridg.nbins);
     {
-        const int nb = std::max(h->ncell, h->gridg.nbins);
+        const int nb = std::max(std::max(h->ncell, h->gridg.nbins), cg.nbins);
         DA(h->scan_tmp, nb / 2048 + 2);
+    }
+    if (!h->small_box) {
+        ClusterBuffers &cb = h->clb;
+        const size_t nslots = (size_t)cg.max_clusters * CL_G;
+        DA(cb.count, cg.nbins); DA(cb.start, cg.nbins + 1); DA(cb.fill, cg.nbins);
+        DA(cb.colncl, cg.ncols + 1); DA(cb.clstart, cg.ncols + 1);
+        DA(cb.order, nslots); DA(cb.ps, nslots);
+        DA(cb.blo, cg.max_clusters); DA(cb.bhi, cg.max_clusters);
+        DA(cb.list, (size_t)cg.max_clusters * cg.list_stride); DA(cb.n0, cg.max_clusters); DA(cb.n1, cg.max_clusters);
     }
     h->gq.assign(L, nullptr); h->ge.assign(L, nullptr); h->dK.assign(L, nullptr); h->dKt.assign(L, nullptr);
     for (int l = 0; l < L; l++) {
@@ -199,9 +244,16 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         HIPCHK(hipMemcpy(h->dKL, h->hp.KL.v.data(), nL * sizeof(double), hipMemcpyHostToDevice));
         DA(h->tmpA, n0 / 2 + 1); DA(h->tmpB, n0 / 4 + 1);
     }
+    h->anterp_tiled = !literal && d.M[0] >= 24 && d.M[1] >= 24 && d.M[2] >= 24;
+    if (h->anterp_tiled) {
+        for (int k = 0; k < 3; k++) h->tiles.nt[k] = (d.M[k] + SPLINE_TILE - 1) / SPLINE_TILE;
+        h->tiles.ntiles = h->tiles.nt[0] * h->tiles.nt[1] * h->tiles.nt[2];
+        const int R = SPLINE_TILE + d.p - 1;
+        DA(h->tile_scratch, (size_t)h->tiles.ntiles * R * R * R);
+    }
     h->nepart = h->small_box ? (N + 63) / 64 : h->ncell;
-    DA(h->epart, h->nepart);
-    DA(h->parts, 4 * NPARTS);
+    DA(h->epart, std::max(h->nepart, cg.max_clusters));
+    DA(h->parts, 5 * NPARTS);
     DA(h->d_energies, MSM_AMD_U_COUNT);
     HIPCHK(hipHostMalloc((void **)&h->h_energies, MSM_AMD_U_COUNT * sizeof(double), hipHostMallocDefault));
 #undef DA
@@ -224,7 +276,12 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     hipStreamSynchronize(h->stream);
     hipFree(h->ps_cell); hipFree(h->ps_grid); hipFree(h->order_cell); hipFree(h->order_grid); hipFree(h->bin_of);
     hipFree(h->slot_idx); hipFree(h->ccount); hipFree(h->cstart); hipFree(h->cfill); hipFree(h->gcount); hipFree(h->gstart);
-    hipFree(h->gfill); hipFree(h->scan_tmp);
+    hipFree(h->gfill); hipFree(h->scan_tmp); hipFree(h->tile_scratch);
+    {
+        ClusterBuffers &cb = h->clb;
+        hipFree(cb.count); hipFree(cb.start); hipFree(cb.fill); hipFree(cb.colncl); hipFree(cb.clstart); hipFree(cb.order);
+        hipFree(cb.ps); hipFree(cb.blo); hipFree(cb.bhi); hipFree(cb.list); hipFree(cb.n0); hipFree(cb.n1);
+    }
     for (auto p : h->gq) hipFree(p);
     for (auto p : h->ge) hipFree(p);
     for (auto p : h->dK) hipFree(p);
@@ -267,6 +324,7 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "pair_variant")) { h->opt_pair_variant = value; return MSM_AMD_OK; }
     if (!strcmp(key, "conv_tiled")) { h->opt_conv_tiled = value; return MSM_AMD_OK; }
     if (!strcmp(key, "conv_small")) { h->opt_conv_small = value; return MSM_AMD_OK; }
+    if (!strcmp(key, "anterp_tiled")) { h->opt_anterp_tiled = value; return MSM_AMD_OK; }
     set_error("unknown option %s", key);
     return MSM_AMD_EINVAL;
 }
@@ -279,9 +337,19 @@ extern "C" int msm_amd_stage_bin(msm_amd_handle *h, const double *d_r, const dou
     if (!h || !d_r || !d_q) { set_error("stage_bin: null argument"); return MSM_AMD_EINVAL; }
     h->cur_r = d_r;
     h->cur_q = d_q;
-    if (!h->small_box)
-        launch_bin(h->stream, d_r, d_q, h->N, h->cellg, h->bin_of, h->ccount, h->cstart, h->cfill, h->slot_idx, h->scan_tmp,
-                   h->order_cell, h->ps_cell);
+    // the sort the selected short-range kernel needs (stage_pairs redoes it if the variant is changed in between)
+    h->cells_binned = false;
+    h->clusters_sorted = false;
+    if (!h->small_box) {
+        if (h->opt_pair_variant >= 5 && h->pp.convention != MSM_AMD_ACC_LITERAL) {
+            launch_cluster_sort(h->stream, d_r, d_q, h->N, h->clg, h->clb, h->bin_of, h->slot_idx, h->scan_tmp);
+            h->clusters_sorted = true;
+        } else {
+            launch_bin(h->stream, d_r, d_q, h->N, h->cellg, h->bin_of, h->ccount, h->cstart, h->cfill, h->slot_idx, h->scan_tmp,
+                       h->order_cell, h->ps_cell);
+            h->cells_binned = true;
+        }
+    }
     launch_bin(h->stream, d_r, d_q, h->N, h->gridg, h->bin_of, h->gcount, h->gstart, h->gfill, h->slot_idx, h->scan_tmp,
                h->order_grid, h->ps_grid);
     HIPCHK(hipGetLastError());
@@ -294,9 +362,21 @@ extern "C" int msm_amd_stage_pairs(msm_amd_handle *h, double *d_acc) {
         int n = 0;
         launch_pair_allimages(h->stream, h->cur_r, h->cur_q, h->N, h->pp, d_acc, h->epart, &n);
         h->nepart = n;
+    } else if (h->opt_pair_variant >= 5 && h->pp.convention != MSM_AMD_ACC_LITERAL) {
+        // cluster pairs (5: neighbour lists, 6: list-free); the unweighted sums of the literal convention exist
+        // only in the cell kernels
+        if (!h->clusters_sorted)
+            launch_cluster_sort(h->stream, h->cur_r, h->cur_q, h->N, h->clg, h->clb, h->bin_of, h->slot_idx, h->scan_tmp);
+        h->clusters_sorted = true;
+        launch_pair_clusters(h->stream, h->clg, h->clb, h->pp, d_acc, h->epart, h->opt_pair_variant - 5);
+        h->nepart = h->clg.max_clusters;
     } else {
+        if (!h->cells_binned)
+            launch_bin(h->stream, h->cur_r, h->cur_q, h->N, h->cellg, h->bin_of, h->ccount, h->cstart, h->cfill, h->slot_idx,
+                       h->scan_tmp, h->order_cell, h->ps_cell);
+        h->cells_binned = true;
         launch_pair_cells(h->stream, h->ps_cell, h->cstart, h->order_cell, h->ncell, h->pp, d_acc, h->epart,
-                          h->opt_pair_variant);
+                          h->opt_pair_variant >= 5 ? 1 : h->opt_pair_variant);
         h->nepart = h->ncell;
     }
     HIPCHK(hipGetLastError());
@@ -305,7 +385,9 @@ extern "C" int msm_amd_stage_pairs(msm_amd_handle *h, double *d_acc) {
 
 extern "C" int msm_amd_stage_anterpolate(msm_amd_handle *h) {
     if (!h || !h->cur_r) { set_error("stage_anterpolate: bin first"); return MSM_AMD_EINVAL; }
-    launch_anterp(h->stream, h->ps_grid, h->gstart, h->sp, h->gq[0]);
+    if (!(h->anterp_tiled && h->opt_anterp_tiled &&
+          launch_anterp_tiled(h->stream, h->ps_grid, h->gstart, h->sp, h->tiles, h->tile_scratch, h->gq[0])))
+        launch_anterp(h->stream, h->ps_grid, h->gstart, h->sp, h->gq[0]);
     HIPCHK(hipGetLastError());
     return MSM_AMD_OK;
 }
@@ -409,6 +491,10 @@ static int queue_energies(msm_amd_handle *h, bool raw = false) {
     launch_charge_partials(h->stream, h->cur_q, (size_t)h->n_owned, pc, NPARTS);
     EnergyInputs in;
     in.pair_parts = h->epart; in.n_pair = h->nepart;
+    if (h->nepart > 8 * NPARTS) { // one block sums these lists: shorten a long one first
+        launch_sum_partials(h->stream, h->epart, h->nepart, h->parts + 4 * NPARTS, NPARTS);
+        in.pair_parts = h->parts + 4 * NPARTS; in.n_pair = NPARTS;
+    }
     in.grid_parts = pg; in.n_grid = NPARTS;
     in.four_parts = pf; in.n_four = NPARTS;
     in.charge_parts = pc; in.n_charge = NPARTS;

@@ -52,6 +52,35 @@ static double bspline_rec(int k, double u) {
     return u / (double)(k - 1) * bspline_rec(k - 1, u) + (k - u) / (double)(k - 1) * bspline_rec(k - 1, u - 1.0);
 }
 
+// The centred B-spline of order p on the k-th unit interval of its support, as a polynomial in the offset f
+// from the interval's left end: Phi(f + p/2 - 1 - k) = B_p(f + u), u = p - 1 - k, and
+// B_p(v) = 1/(p-1)! sum_j (-1)^j C(p,j) (v - j)_+^(p-1)  (the closed pieces of msm/msmLibrary.h:120-142).
+void spline_pieces(int p, double piece[6][6], double dpiece[6][6]) {
+    for (int k = 0; k < 6; k++)
+        for (int n = 0; n < 6; n++) piece[k][n] = dpiece[k][n] = 0.0;
+    auto binom = [](int n, int k) {
+        long double c = 1.0L;
+        for (int i = 1; i <= k; i++) c = c * (n - k + i) / i;
+        return c;
+    };
+    long double fact = 1.0L;
+    for (int i = 2; i <= p - 1; i++) fact *= i;
+    for (int k = 0; k < p; k++) {
+        const int u = p - 1 - k;
+        long double c[6] = {0, 0, 0, 0, 0, 0};
+        for (int j = 0; j <= u; j++) {
+            const long double sgn = (j & 1) ? -1.0L : 1.0L, m = (long double)(u - j);
+            for (int n = 0; n <= p - 1; n++) {
+                long double mp = 1.0L; // m^(p-1-n), with 0^0 = 1
+                for (int e = 0; e < p - 1 - n; e++) mp *= m;
+                c[n] += sgn * binom(p, j) * binom(p - 1, n) * mp;
+            }
+        }
+        for (int n = 0; n <= p - 1; n++) piece[k][n] = (double)(c[n] / fact);
+        for (int n = 0; n + 1 <= p - 1; n++) dpiece[k][n] = (double)((n + 1) * c[n + 1] / fact);
+    }
+}
+
 // J_j = C(p, p/2 + j) / 2^(p-1)   (msm/msmLibrary.h:152-153)
 void two_scale(int p, double J[4]) {
     for (int j = 0; j < 4; j++) J[j] = 0.0;

@@ -36,6 +36,7 @@ struct HostPlan {
 //   gamma(rho)      = sum_k cg[k] x^k            (rho < 1)
 //   -gamma'(rho)/rho = sum_k cd[k] x^k           (rho < 1)
 void gamma_poly(int p, double cg[8], double cd[8]);
+void spline_pieces(int p, double piece[6][6], double dpiece[6][6]);
 double gamma_eval(double rho, int p);
 
 std::vector<double> compute_wprime(int p, int mu);

@@ -10,26 +10,11 @@
 //   interpolation  k_interp           one thread per particle (msmPeriodic.c:1116-1161)
 //   reductions     k_dot_partials, k_charge_partials, k_finalize_energies (msmPeriodic.c:1305-1359)
 #include "msm_kernels.hpp"
+#include "msm_device.hpp"
 
 #include "msm_amd.h"
 
 namespace msm {
-
-// Blocks b and b+8 share an XCD (and its L2).  Give each XCD a contiguous run of
-// logical ids so that neighbouring tiles / cells, which share halo data, meet in one L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, k = bid >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-}
-
-__device__ __forceinline__ int wrap1(int i, int M) { // i in [-M, 2M)
-    i = (i < 0) ? i + M : i;
-    return (i >= M) ? i - M : i;
-}
-__device__ __forceinline__ int modp(int i, int M) {
-    int r = i % M;
-    return r < 0 ? r + M : r;
-}
 
 // ---------------------------------------------------------------------------
 // binning
@@ -161,6 +146,19 @@ __global__ void k_bin_finalize(const double *__restrict__ r, const double *__res
     ps[dst] = make_double4(f[0] * g.scale[0], f[1] * g.scale[1], f[2] * g.scale[2], q[i]);
 }
 
+// out[0..n] = exclusive prefix sums of in[0..n) (out[n] = total); scan_tmp holds n/SCAN_TILE + 1 ints
+void launch_exclusive_scan(hipStream_t st, const int *in, int n, int *scan_tmp, int *out) {
+    const int ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(SCAN_THREADS), 0, st, in, n, scan_tmp);
+    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(SCAN_THREADS), 0, st, scan_tmp, ntiles);
+    hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(SCAN_THREADS), 0, st, in, n, scan_tmp, out);
+}
+
+void launch_bin_scatter(hipStream_t st, const int *bin_of, int N, const int *start, int *fill, int *slot_idx) {
+    const int tb = 256, gb = (N + tb - 1) / tb;
+    hipLaunchKernelGGL(k_bin_scatter, dim3(gb), dim3(tb), 0, st, bin_of, N, start, fill, slot_idx);
+}
+
 void launch_bin(hipStream_t st, const double *d_r, const double *d_q, int N, const BinGeom &g, int *bin_of, int *count,
                 int *start, int *fill, int *slot_idx, int *scan_tmp, int *order, double4 *ps) {
     const int nb = g.nbins;
@@ -168,11 +166,8 @@ void launch_bin(hipStream_t st, const double *d_r, const double *d_q, int N, con
     hipMemsetAsync(fill, 0, sizeof(int) * (size_t)nb, st);
     const int tb = 256, gb = (N + tb - 1) / tb;
     hipLaunchKernelGGL(k_bin_count, dim3(gb), dim3(tb), 0, st, d_r, N, g, bin_of, count);
-    const int ntiles = (nb + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(ntiles), dim3(SCAN_THREADS), 0, st, count, nb, scan_tmp);
-    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(SCAN_THREADS), 0, st, scan_tmp, ntiles);
-    hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(SCAN_THREADS), 0, st, count, nb, scan_tmp, start);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(gb), dim3(tb), 0, st, bin_of, N, start, fill, slot_idx);
+    launch_exclusive_scan(st, count, nb, scan_tmp, start);
+    launch_bin_scatter(st, bin_of, N, start, fill, slot_idx);
     hipLaunchKernelGGL(k_bin_finalize, dim3(gb), dim3(tb), 0, st, d_r, d_q, N, g, bin_of, start, slot_idx, order, ps);
 }
 
@@ -400,12 +395,6 @@ __device__ __forceinline__ int row_segments(const PairParams &pp, const int *__r
         seg[o + 1].sx = sx; seg[o + 1].sy = sy; seg[o + 1].sz = sz;
     }
     return 3;
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
 }
 
 template <int P, bool UNW>
@@ -1144,6 +1133,20 @@ __global__ __launch_bounds__(256) void k_charge_partials(const double *__restric
 }
 void launch_charge_partials(hipStream_t st, const double *q, size_t n, double *parts, int nparts) {
     hipLaunchKernelGGL(k_charge_partials, dim3(nparts), dim3(256), 0, st, q, n, parts, nparts);
+}
+
+// parts[b] = sum of block b's contiguous share of in[0..n): shortens a long list of partial sums in a fixed order
+__global__ __launch_bounds__(256) void k_sum_partials(const double *__restrict__ in, int n, double *__restrict__ parts) {
+    __shared__ double red[256];
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(n, lo + per);
+    double s = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) s += in[i];
+    const double t = block_sum<256>(s, red);
+    if (threadIdx.x == 0) parts[blockIdx.x] = t;
+}
+void launch_sum_partials(hipStream_t st, const double *in, int n, double *parts, int nparts) {
+    hipLaunchKernelGGL(k_sum_partials, dim3(nparts), dim3(256), 0, st, in, n, parts);
 }
 
 __device__ double sum_array(const double *__restrict__ p, int n, double *red) {

@@ -24,6 +24,8 @@ struct PairParams {
     double inv_a3;   // 1/a^3
     double cg[8];    // gamma(rho)       = sum cg[k] y^k, y = rho^2-1
     double cd[8];    // -gamma'(rho)/rho = sum cd[k] y^k
+    double cga[8];   // cg / a   (gamma(rho)/a as a polynomial in y)
+    double cda[8];   // cd / a^3
     int p;
     int convention;  // MSM_AMD_ACC_*
     int n_owned;     // particles with original index >= n_owned are halo copies: no output for them
@@ -43,11 +45,55 @@ struct SplineParams {
     int z0, nz;        // owned z planes [z0, z0+nz)
     int convention;
     int n_owned;
+    // piece[k][n]: coefficient of f^n of the weight of the k-th node of a particle's support, f in [0,1) the
+    // fractional grid coordinate: Phi(f + p/2 - 1 - k) = sum_n piece[k][n] f^n; dpiece = d/df of the same
+    double piece[6][6];
+    double dpiece[6][6];
+};
+
+// tiles of SPLINE_TILE^3 grid cells for the LDS-tiled anterpolation
+#define SPLINE_TILE 8
+struct TileGeom {
+    int nt[3];
+    int ntiles;
 };
 
 // ---- binning ----
 void launch_bin(hipStream_t st, const double *d_r, const double *d_q, int N, const BinGeom &g, int *bin_of, int *count,
                 int *start, int *fill, int *slot_idx, int *scan_tmp, int *order, double4 *ps);
+void launch_exclusive_scan(hipStream_t st, const int *in, int n, int *scan_tmp, int *out);
+void launch_bin_scatter(hipStream_t st, const int *bin_of, int N, const int *start, int *fill, int *slot_idx);
+
+// ---- cluster pairs ----
+// Particles are sorted into columns (x, y) and by z inside a column, then cut into clusters of CL_G consecutive
+// particles; a column's last cluster is padded with inert slots so that no cluster straddles two columns.
+#define CL_G 8
+struct ClusterGeom {
+    int ncx, ncy, nzf;   // columns along x and y, fine z bins per column
+    int ncols, nbins;    // ncx*ncy, ncols*nzf
+    int max_clusters;    // capacity of the per-cluster arrays: ceil(N/CL_G) + ncols
+    int list_stride;     // list entries reserved per cluster
+    double invA[3], A[3];
+    double inv_pitch[2]; // columns per unit length
+    double pitch[2];
+    double inv_dzf, dzf; // fine bins per unit length in z
+    double far;          // coordinate given to padding slots
+};
+struct ClusterBuffers {
+    int *count, *start, *fill;  // per fine bin (start has nbins + 1 entries)
+    int *colncl, *clstart;      // clusters per column and their exclusive scan (ncols + 1; last = cluster count)
+    int *order;                 // original particle index per slot, CL_DUMMY for padding
+    double4 *ps;                // (x, y, z, q) per slot, absolute coordinates in [0, A)
+    double4 *blo, *bhi;         // cluster bounding boxes
+    int *list, *n0, *n1;        // neighbour-cluster lists: n0 unshifted entries from the front, n1 shifted from the back
+};
+void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, int N, const ClusterGeom &g,
+                         const ClusterBuffers &b, int *bin_of, int *slot_idx, int *scan_tmp);
+// variant 0: build lists, then one wave per cluster walks its list; variant 1: no lists, every wave enumerates and
+// evaluates its candidates directly.  Clusters whose list overflowed list_stride are evaluated by the direct kernel.
+void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double *acc,
+                          double *epart, int variant);
+
 // ---- short range ----
 void launch_pair_cells(hipStream_t st, const double4 *ps, const int *cstart, const int *order, int ncell,
                        const PairParams &pp, double *acc, double *epart, int variant);
@@ -55,6 +101,10 @@ void launch_pair_allimages(hipStream_t st, const double *d_r, const double *d_q,
                            double *epart, int *nepart);
 // ---- grid transfer ----
 void launch_anterp(hipStream_t st, const double4 *ps_grid, const int *gstart, const SplineParams &sp, double *grid);
+// LDS-tiled form; scratch holds ntiles * (SPLINE_TILE + p - 1)^3 doubles.  Needs M >= 24 on every axis and the
+// plain index convention (no node_shift / drop_last).
+bool launch_anterp_tiled(hipStream_t st, const double4 *ps_grid, const int *gstart, const SplineParams &sp, const TileGeom &tl,
+                         double *scratch, double *grid);
 void launch_interp(hipStream_t st, const double4 *ps_grid, const int *order, int N, const SplineParams &sp,
                    const double *egrid, int index_shift, double *acc);
 // one axis of the separable restriction: out has the axis halved.  J[0..p/2]
@@ -80,6 +130,7 @@ void launch_axpy(hipStream_t st, double *y, const double *x, size_t n);
 void launch_dot_partials(hipStream_t st, const double *a, const double *b, size_t n, double *parts, int nparts);
 // parts of sum q and sum q^2 -> parts[0..nparts), parts[nparts..2 nparts)
 void launch_charge_partials(hipStream_t st, const double *q, size_t n, double *parts, int nparts);
+void launch_sum_partials(hipStream_t st, const double *in, int n, double *parts, int nparts);
 struct EnergyInputs {
     const double *pair_parts; int n_pair;       // sum = (A)
     const double *grid_parts; int n_grid;       // 1/2 q0.e0

@@ -55,6 +55,7 @@ CASES = [  # (N, box, p, mu, L)
     (3000, (1.0, 1.0, 1.0), 6, 6, 2),
     (20000, (1.0, 1.0, 1.0), 4, 10, 2),    # M=32: compact 15^3 stencil at level 0 -> tiled kernel
     (20000, (1.3, 0.9, 1.1), 4, 10, 2),    # non-cubic cell
+    (20000, (1.0, 1.0, 1.0), 6, 6, 2),     # quintic spline on a grid large enough for the tiled anterpolation
     (300, (1.0, 1.0, 1.0), 4, 10, 1),      # small box: all-images pair kernel
     (64, (2.0, 2.0, 2.0), 6, 4, 1),
 ]
@@ -158,21 +159,51 @@ def test_pair_kernel_variants_agree(msm, torch):
     eng = msm.Engine(desc)
     rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
     out = []
-    for v in (1, 2, 3, 4):
+    for v in (1, 2, 3, 4, 5, 6):     # 1-4: cell lists; 5: cluster pairs with lists; 6: cluster pairs, list-free
         eng.set_option("pair_variant", v)
         en, acc = eng.eval(rd, qd)
         out.append((en.copy(), acc.cpu().numpy().copy()))
-    for k in (1, 2, 3):
+    for k in (1, 2, 3, 4, 5):
         assert rel_rms(out[k][1], out[0][1]) < 1e-13
         assert abs(out[k][0][0] - out[0][0][0]) < 1e-13 * abs(out[0][0][0])
     sp = spec_for(desc)
     aw, au, ureal = sp.pairs(r, q)
-    for v in (2, 3, 4):
+    for v in (1, 2, 3, 4, 5, 6):
         eng.set_option("pair_variant", v)
         eng.stage_bin(rd, qd)
         a2 = torch.zeros((N, 3), dtype=torch.float64, device="cuda:0")
         eng.stage_pairs(a2)
         assert rel_rms(a2.cpu().numpy(), aw) < TOL
+
+
+@pytest.mark.parametrize("p,M", [(4, (28, 36, 26)), (6, (26, 24, 41)), (4, (24, 24, 24)), (6, (32, 40, 48))])
+def test_anterpolation_tiled(msm, torch, p, M):
+    """LDS-tiled anterpolation (grids >= 24 per axis) against the oracle and against the gather kernel, on grid
+    sizes that are not multiples of the tile edge, with particles on cell faces and on the period boundary."""
+    N, A = 15000, (1.0, 1.2, 0.9)
+    r, q = O.neutral_system(N, A, seed=5 + p)
+    r[:50] = np.floor(r[:50] / np.array(A) * np.array(M)) * np.array(A) / np.array(M)   # on grid nodes
+    r[50] = [0.0, 0.0, 0.0]
+    r[51] = [A[0] * (1 - 1e-17), A[1] * (1 - 1e-16), A[2]]
+    d = msm.plan_explicit(N, A, M, p, 6, 1, 0.12, 20.0, 8)
+    eng = msm.Engine(d)
+    sp = spec_for(d)
+    rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
+    want = sp.anterpolate(r, q)
+    got = {}
+    for tiled in (1, 0):
+        eng.set_option("anterp_tiled", tiled)
+        eng.stage_bin(rd, qd)
+        eng.stage_anterpolate()
+        got[tiled] = eng.grid(msm.capi.GRID_Q, 0)
+        assert grid_err(got[tiled], want) < TOL, tiled
+    assert grid_err(got[1], got[0]) < 1e-13
+    eng.set_option("anterp_tiled", 1)
+    eng.stage_bin(rd, qd)
+    eng.stage_anterpolate()
+    assert np.array_equal(eng.grid(msm.capi.GRID_Q, 0), got[1])   # reproducible
+    eng.close()
+    sp.close()
 
 
 def test_conventions(msm, torch):
@@ -301,11 +332,11 @@ def test_edge_cases(msm, torch):
     eng = msm.Engine(d)
     sp = spec_for(d)
     ref = sp.eval(r, q)
-    for v in (1, 2, 3, 4):
+    for v in (1, 2, 3, 4, 5, 6):   # the crowded region overflows the cluster lists: the list-free kernel takes over
         eng.set_option("pair_variant", v)
         en, acc = eng.eval(r, q)
-        assert np.abs(en - ref["energies"]).max() < TOL * np.abs(ref["energies"][:6]).max()
-        assert rel_rms(acc.cpu().numpy(), ref["acc"]) < TOL
+        assert np.abs(en - ref["energies"]).max() < TOL * np.abs(ref["energies"][:6]).max(), v
+        assert rel_rms(acc.cpu().numpy(), ref["acc"]) < TOL, v
     eng.close()
     # invalid plans fail loudly
     bad = msm.plan_explicit(10, (1.0, 1.0, 1.0), (6, 6, 6), 4, 10, 3, 0.3, 3.0, 5)  # 6 not divisible by 4
@@ -340,10 +371,10 @@ def test_full_size_properties(msm, torch):
     en2, acc2 = eng.eval(rd, qd)
     assert np.array_equal(en, en2) and np.array_equal(acc, acc2.cpu().numpy())
     # the pair kernel variants agree at full size
-    for v in (1, 2, 3, 4):
+    for v in (1, 2, 3, 4, 6, 5):
         eng.set_option("pair_variant", v)
         en3, acc3 = eng.eval(rd, qd)
-        assert rel_rms(acc3.cpu().numpy(), acc) < 1e-13
+        assert rel_rms(acc3.cpu().numpy(), acc) < 1e-13, v
     # invariance under a lattice translation of some particles and under relabelling
     r2 = r.copy()
     r2[::7] += np.array([1.0, -2.0, 3.0])
