@@ -475,7 +475,10 @@ extern "C" int msm_amd_stage_interpolate(msm_amd_handle *h, double *d_acc) {
     if (!h || !d_acc || !h->cur_r) { set_error("stage_interpolate: bin first"); return MSM_AMD_EINVAL; }
     // literal: grid index = node + p/2 - 1 (msmPeriodic.c:1136-1151)
     const int shift = h->hp.literal ? h->hp.d.p / 2 - 1 : 0;
-    launch_interp(h->stream, h->ps_grid, h->order_grid, h->N, h->sp, h->ge[0], shift, d_acc);
+    if (h->anterp_tiled && h->opt_anterp_tiled)
+        launch_interp_tiled(h->stream, h->ps_grid, h->order_grid, h->gstart, h->sp, h->tiles, h->ge[0], d_acc);
+    else
+        launch_interp(h->stream, h->ps_grid, h->order_grid, h->N, h->sp, h->ge[0], shift, d_acc);
     HIPCHK(hipGetLastError());
     return MSM_AMD_OK;
 }

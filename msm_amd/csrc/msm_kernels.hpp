@@ -105,6 +105,8 @@ void launch_anterp(hipStream_t st, const double4 *ps_grid, const int *gstart, co
 // plain index convention (no node_shift / drop_last).
 bool launch_anterp_tiled(hipStream_t st, const double4 *ps_grid, const int *gstart, const SplineParams &sp, const TileGeom &tl,
                          double *scratch, double *grid);
+void launch_interp_tiled(hipStream_t st, const double4 *ps_grid, const int *order, const int *gstart, const SplineParams &sp,
+                         const TileGeom &tl, const double *egrid, double *acc);
 void launch_interp(hipStream_t st, const double4 *ps_grid, const int *order, int N, const SplineParams &sp,
                    const double *egrid, int index_shift, double *acc);
 // one axis of the separable restriction: out has the axis halved.  J[0..p/2]

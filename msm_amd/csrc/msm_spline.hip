@@ -129,6 +129,112 @@ __global__ __launch_bounds__(256) void k_anterp_combine(const double *__restrict
     grid[((size_t)jz * My + jy) * Mx + jx] = sum;
 }
 
+// Interpolation of the level-0 potentials back to the particles (msmPeriodic.c:1116-1161, msmSimple.c:1317-1380),
+// tile by tile: the workgroup of a tile stages the (8 + p - 1)^3 block of potentials its particles touch in LDS
+// (periodic wrap applied while staging), then every thread takes one particle of the tile and sums its p^3
+// nodes out of LDS.  acc_i += f sum_m e_m grad Phi_m(r_i), f by the acceleration convention.
+template <int P>
+__global__ __launch_bounds__(256) void k_interp_tiles(const double4 *__restrict__ ps, const int *__restrict__ order,
+                                                      const int *__restrict__ gstart, SplineParams sp, TileGeom tl,
+                                                      const double *__restrict__ e, double *__restrict__ acc) {
+    constexpr int R = AT + P - 1, R3 = R * R * R;
+    __shared__ double blk[R3];
+    __shared__ int rowstart[AT * AT + 1], rowbase[AT * AT];
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tx = tile % tl.nt[0], ty = (tile / tl.nt[0]) % tl.nt[1], tz = tile / (tl.nt[0] * tl.nt[1]);
+    const int Mx = sp.M[0], My = sp.M[1], Mz = sp.M[2];
+    const int x0 = tx * AT, y0 = ty * AT, z0 = tz * AT;
+    const int nxc = min(AT, Mx - x0), nyc = min(AT, My - y0), nzc = min(AT, Mz - z0);
+    const int nrows = nyc * nzc;
+    if (threadIdx.x < 64) { // rows of the tile: first particle and running count (one wave, shuffle scan)
+        const int t = threadIdx.x;
+        int cnt = 0;
+        if (t < nrows) {
+            const int b0 = ((z0 + t / nyc) * My + (y0 + t % nyc)) * Mx + x0;
+            const int s0 = gstart[b0];
+            rowbase[t] = s0;
+            cnt = gstart[b0 + nxc] - s0;
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (t >= off) incl += v;
+        }
+        if (t < nrows) rowstart[t + 1] = incl;
+        if (t == 0) rowstart[0] = 0;
+    }
+    __syncthreads();
+    const int total = rowstart[nrows];
+    if (total == 0) return;
+    for (int t = threadIdx.x; t < R3; t += 256) {
+        const int lx = t % R, ly = (t / R) % R, lz = t / (R * R);
+        const int gx = modp(x0 - (P / 2 - 1) + lx, Mx), gy = modp(y0 - (P / 2 - 1) + ly, My), gz = modp(z0 - (P / 2 - 1) + lz, Mz);
+        blk[t] = e[((size_t)gz * My + gy) * Mx + gx];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        int lo = 0, hi = nrows; // row with rowstart[row] <= idx < rowstart[row+1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (rowstart[mid] <= idx) lo = mid; else hi = mid;
+        }
+        const int s = rowbase[lo] + (idx - rowstart[lo]);
+        const int orig = order[s];
+        if (orig >= sp.n_owned) continue;
+        const double4 pt = ps[s];
+        const int ry = lo % nyc, rz = lo / nyc;
+        const int cellx = min((int)pt.x, Mx - 1);
+        const double f[3] = {pt.x - (double)cellx, pt.y - (double)(y0 + ry), pt.z - (double)(z0 + rz)};
+        double w[2][P], dw[2][P]; // x and y weights; the z weights are made plane by plane
+#pragma unroll
+        for (int d = 0; d < 2; d++)
+#pragma unroll
+            for (int v = 0; v < P; v++) {
+                w[d][v] = piece_eval<P>(sp.piece[v], f[d]);
+                dw[d][v] = piece_eval<P - 1>(sp.dpiece[v], f[d]);
+            }
+        const double *__restrict__ b0 = blk + (rz * R + ry) * R + (cellx - x0);
+        double gx = 0, gy = 0, gz = 0;
+#pragma unroll 1
+        for (int c = 0; c < P; c++) {
+            const double wz = piece_eval<P>(sp.piece[c], f[2]), dwz = piece_eval<P - 1>(sp.dpiece[c], f[2]);
+            double px = 0, py = 0, pv = 0; // plane sums: d/dx, d/dy, value
+#pragma unroll
+            for (int b = 0; b < P; b++) {
+                const double *row = b0 + (c * R + b) * R;
+                double sv = 0, sd = 0; // sum_a w_a e, sum_a dw_a e along x
+#pragma unroll
+                for (int a = 0; a < P; a++) {
+                    const double ev = row[a];
+                    sv = fma(w[0][a], ev, sv);
+                    sd = fma(dw[0][a], ev, sd);
+                }
+                px = fma(w[1][b], sd, px);
+                py = fma(dw[1][b], sv, py);
+                pv = fma(w[1][b], sv, pv);
+            }
+            gx = fma(wz, px, gx);
+            gy = fma(wz, py, gy);
+            gz = fma(dwz, pv, gz);
+        }
+        gx *= sp.inv_h[0]; gy *= sp.inv_h[1]; gz *= sp.inv_h[2];
+        double fac = 1.0;
+        if (sp.convention == MSM_AMD_ACC_LITERAL) fac = pt.w;
+        else if (sp.convention == MSM_AMD_ACC_FORCE) fac = -pt.w;
+        const size_t o = 3 * (size_t)orig;
+        acc[o] += fac * gx;
+        acc[o + 1] += fac * gy;
+        acc[o + 2] += fac * gz;
+    }
+}
+
+void launch_interp_tiled(hipStream_t st, const double4 *ps_grid, const int *order, const int *gstart, const SplineParams &sp,
+                         const TileGeom &tl, const double *egrid, double *acc) {
+    if (sp.p == 4) hipLaunchKernelGGL((k_interp_tiles<4>), dim3(tl.ntiles), dim3(256), 0, st, ps_grid, order, gstart, sp, tl, egrid, acc);
+    else hipLaunchKernelGGL((k_interp_tiles<6>), dim3(tl.ntiles), dim3(256), 0, st, ps_grid, order, gstart, sp, tl, egrid, acc);
+}
+
 bool launch_anterp_tiled(hipStream_t st, const double4 *ps_grid, const int *gstart, const SplineParams &sp, const TileGeom &tl,
                          double *scratch, double *grid) {
     const size_t n = (size_t)sp.M[0] * sp.M[1] * sp.nz;
