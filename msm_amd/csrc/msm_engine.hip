@@ -57,7 +57,7 @@ struct msm_amd_handle {
     hipEvent_t ev[T_COUNT + 1];
     bool ev_made = false;
     double last_ms[T_COUNT];
-    int opt_pair_variant = 5, opt_conv_tiled = 1, opt_conv_small = 1;
+    int opt_pair_variant = 5, opt_conv_tiled = 2, opt_conv_small = 1; // conv_tiled: 0 off, 1 per level, 2 levels share a launch
     // cluster-pair path of the short-range sum
     ClusterGeom clg;
     ClusterBuffers clb = {};
@@ -427,24 +427,51 @@ extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
         launch_restrict_axis(st, h->tmpB, h->gq[l + 1], m2, 2, p, h->hp.J);
     }
     mark(h, T_CONV);
+    // plane ranges to convolve per level: everything, except on a slab rank's level 0, where the potentials are
+    // needed on the owned planes plus p/2 planes either side (interpolation support) and the other planes of
+    // ge[0] are left at zero
+    struct Range { int l, z0, nz; };
+    std::vector<Range> ranges;
     for (int l = 0; l < L; l++) {
         if (l == 0 && d.nzplanes < d.M[2]) {
-            // slab rank: level-0 potentials are needed on the owned planes plus p/2 planes either side
-            // (interpolation support); other planes of ge[0] are left untouched.
             const int hz = p / 2, Mz = d.M[2];
             int lo = d.zplane0 - hz, n = d.nzplanes + 2 * hz;
             hipMemsetAsync(h->ge[0], 0, sizeof(double) * (size_t)d.M[0] * d.M[1] * Mz, st);
-            if (n >= Mz) { convolve_level(h, 0, h->gq[0], h->ge[0], 0, Mz); }
+            if (n >= Mz) ranges.push_back({0, 0, Mz});
             else {
                 lo = ((lo % Mz) + Mz) % Mz;
                 const int first = std::min(n, Mz - lo);
-                convolve_level(h, 0, h->gq[0], h->ge[0], lo, first);
-                if (n > first) convolve_level(h, 0, h->gq[0], h->ge[0], 0, n - first);
+                ranges.push_back({0, lo, first});
+                if (n > first) ranges.push_back({0, 0, n - first});
             }
         } else {
-            convolve_level(h, l, h->gq[l], h->ge[l], 0, h->hp.Ml[l][2]);
+            ranges.push_back({l, 0, h->hp.Ml[l][2]});
         }
     }
+    // the large ones share one launch of the multi-level tiled kernel
+    std::vector<bool> done(ranges.size(), false);
+    if (!h->hp.literal && h->opt_conv_tiled >= 2) {
+        ConvBatch B;
+        B.n = 0;
+        std::vector<size_t> members;
+        for (size_t i = 0; i < ranges.size() && B.n < 8; i++) {
+            const Range &r = ranges[i];
+            const LevelStencil &S = h->hp.K[r.l];
+            const int *M = h->hp.Ml[r.l];
+            if (!(M[0] >= 16 && M[1] >= 8 && r.nz >= 8)) continue;
+            if (B.n > 0 && S.size[2] != B.c[0].ks[2]) continue;
+            ConvArgs &c = B.c[B.n];
+            for (int k = 0; k < 3; k++) { c.M[k] = M[k]; c.ks[k] = S.size[k]; c.kf[k] = S.first[k]; }
+            c.z0 = r.z0; c.nz = r.nz; c.accumulate = 0;
+            B.q[B.n] = h->gq[r.l]; B.Kt[B.n] = h->dKt[r.l]; B.e[B.n] = h->ge[r.l];
+            B.n++;
+            members.push_back(i);
+        }
+        if (B.n > 0 && launch_conv_multi(st, B))
+            for (size_t i : members) done[i] = true;
+    }
+    for (size_t i = 0; i < ranges.size(); i++)
+        if (!done[i]) convolve_level(h, ranges[i].l, h->gq[ranges[i].l], h->ge[ranges[i].l], ranges[i].z0, ranges[i].nz);
     mark(h, T_TOP);
     {
         const int *ML = h->hp.Ml[L - 1];

@@ -10,6 +10,7 @@
 //   interpolation  k_interp           one thread per particle (msmPeriodic.c:1116-1161)
 //   reductions     k_dot_partials, k_charge_partials, k_finalize_energies (msmPeriodic.c:1305-1359)
 #include "msm_kernels.hpp"
+#include <algorithm>
 #include "msm_device.hpp"
 
 #include "msm_amd.h"
@@ -892,10 +893,6 @@ void launch_prolong_axis(hipStream_t st, const double *in, double *out, const in
 // ---------------------------------------------------------------------------
 // grid convolution
 // ---------------------------------------------------------------------------
-struct ConvArgs {
-    int M[3], ks[3], kf[3];
-    int z0, nz, accumulate;
-};
 
 __global__ __launch_bounds__(256) void k_conv_direct(const double *__restrict__ q, const double *__restrict__ K,
                                                      double *__restrict__ e, ConvArgs c) {
@@ -1039,6 +1036,149 @@ bool launch_conv_tiled(hipStream_t st, const double *q, const double *Kt, const 
     case S:                                                                                    \
         if (conv_tiled_launch<S, 4, 16, 8, 8>(st, q, Kt, e, c)) return true;                   \
         return conv_tiled_launch<S, 4, 16, 4, 8>(st, q, Kt, e, c);
+        CASE_SZ(7)
+        CASE_SZ(9)
+        CASE_SZ(11)
+        CASE_SZ(13)
+        CASE_SZ(15)
+        CASE_SZ(17)
+        CASE_SZ(19)
+#undef CASE_SZ
+    default:
+        return false;
+    }
+}
+
+// Several levels in one launch.  The convolutions of the grid levels are independent of each other and only
+// the finest one is large enough to fill the chip, so they share a launch: block -> (level, tile).  A thread
+// owns R consecutive outputs along z; for every (sx, sy) it reads a window of R + SZ - 1 inputs from the LDS
+// tile and feeds R * SZ FMAs whose stencil taps are wave-uniform (scalar loads).  With one wave per SIMD (the
+// tile takes almost all of the LDS) nothing else hides latency, so the window and the taps of the next
+// (sx, sy) are fetched before the FMAs of the current one are issued.
+template <int SZ, int R, int TX, int TY, int TZ>
+__global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
+    extern __shared__ double lds[];
+    int lev = 0;
+    while (lev + 1 < B.n && (int)blockIdx.x >= B.blk0[lev + 1]) lev++;
+    const ConvArgs c = B.c[lev];
+    const double *__restrict__ q = B.q[lev];
+    const double *__restrict__ Kt = B.Kt[lev];
+    double *__restrict__ e = B.e[lev];
+    const int ntx = B.ntx[lev], nty = B.nty[lev];
+    const int Mx = c.M[0], My = c.M[1], Mz = c.M[2];
+    const int sxn = c.ks[0], syn = c.ks[1];
+    const int LX = TX + sxn - 1, LY = TY + syn - 1, LZ = TZ + SZ - 1;
+    const int bid = blockIdx.x - B.blk0[lev];
+    const int bx = bid % ntx, by = (bid / ntx) % nty, bz = bid / (ntx * nty);
+    const int X0 = bx * TX, Y0 = by * TY, Z0 = c.z0 + bz * TZ;
+    const int ox = X0 - (c.kf[0] + sxn - 1), oy = Y0 - (c.kf[1] + syn - 1), oz = Z0 - (c.kf[2] + SZ - 1);
+    constexpr int NT = TX * TY * (TZ / R);
+    for (int t = threadIdx.x; t < LX * LY * LZ; t += NT) {
+        const int lx = t % LX, ly = (t / LX) % LY, lz = t / (LX * LY);
+        lds[t] = q[((size_t)modp(oz + lz, Mz) * My + modp(oy + ly, My)) * Mx + modp(ox + lx, Mx)];
+    }
+    __syncthreads();
+    const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) % TY, tg = threadIdx.x / (TX * TY);
+    constexpr int W = R + SZ - 1;
+    const int plane = LY * LX;
+    const double *col0 = lds + (size_t)(tg * R) * plane + (ty + syn - 1) * LX + (tx + sxn - 1);
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.0;
+    double va[W], vb[W], ka[SZ], kb[SZ];
+    const int ntaps = sxn * syn;
+#pragma unroll
+    for (int w = 0; w < W; w++) va[w] = col0[w * plane];
+#pragma unroll
+    for (int z = 0; z < SZ; z++) ka[z] = Kt[z];
+    int sx = 0, sy = 0; // tap t = sy * sxn + sx
+    for (int t = 0; t < ntaps; t += 2) {
+        // fetch tap t + 1 into the b registers
+        int sx1 = sx + 1, sy1 = sy;
+        if (sx1 == sxn) { sx1 = 0; sy1++; }
+        const bool has1 = t + 1 < ntaps;
+        // The window and taps of tap t were fetched a whole block ago: wait for them now, before the next
+        // fetches are issued (scalar loads return out of order, so a later wait would have to be a full one
+        // and would expose the latency of the new fetches).
+        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const double *col = col0 - (has1 ? sy1 * LX + sx1 : 0);
+            const double *kk = Kt + (size_t)(has1 ? t + 1 : 0) * SZ;
+#pragma unroll
+            for (int w = 0; w < W; w++) vb[w] = col[w * plane];
+#pragma unroll
+            for (int z = 0; z < SZ; z++) kb[z] = kk[z];
+        }
+        __builtin_amdgcn_sched_barrier(0); // keep the fetches above ahead of the FMAs below
+#pragma unroll
+        for (int z = 0; z < SZ; z++)
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = fma(ka[z], va[r + SZ - 1 - z], acc[r]);
+        if (!has1) break;
+        // fetch tap t + 2 into the a registers
+        int sx2 = sx1 + 1, sy2 = sy1;
+        if (sx2 == sxn) { sx2 = 0; sy2++; }
+        const bool has2 = t + 2 < ntaps;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const double *col = col0 - (has2 ? sy2 * LX + sx2 : 0);
+            const double *kk = Kt + (size_t)(has2 ? t + 2 : 0) * SZ;
+#pragma unroll
+            for (int w = 0; w < W; w++) va[w] = col[w * plane];
+#pragma unroll
+            for (int z = 0; z < SZ; z++) ka[z] = kk[z];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int z = 0; z < SZ; z++)
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = fma(kb[z], vb[r + SZ - 1 - z], acc[r]);
+        sx = sx2;
+        sy = sy2;
+    }
+    const int mx = X0 + tx, my = Y0 + ty;
+    if (mx < Mx && my < My) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int mz = Z0 + tg * R + r;
+            if (mz < c.z0 + c.nz && mz < Mz) e[((size_t)mz * My + my) * Mx + mx] = acc[r];
+        }
+    }
+}
+
+template <int SZ, int R, int TX, int TY, int TZ>
+static bool conv_multi_launch(hipStream_t st, ConvBatch &B) {
+    size_t bytes = 0;
+    int nblk = 0;
+    for (int l = 0; l < B.n; l++) {
+        const ConvArgs &c = B.c[l];
+        if (c.ks[2] != SZ) return false;
+        const int LX = TX + c.ks[0] - 1, LY = TY + c.ks[1] - 1, LZ = TZ + SZ - 1;
+        bytes = std::max(bytes, sizeof(double) * (size_t)LX * LY * LZ);
+        B.ntx[l] = (c.M[0] + TX - 1) / TX;
+        B.nty[l] = (c.M[1] + TY - 1) / TY;
+        B.blk0[l] = nblk;
+        nblk += B.ntx[l] * B.nty[l] * ((c.nz + TZ - 1) / TZ);
+    }
+    B.blk0[B.n] = nblk;
+    if (bytes > 160 * 1024 || nblk == 0) return false;
+    auto kern = k_conv_multi<SZ, R, TX, TY, TZ>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(TX * TY * (TZ / R)), bytes, st, B);
+    return true;
+}
+
+bool launch_conv_multi(hipStream_t st, ConvBatch &B) {
+    if (B.n < 1) return false;
+    switch (B.c[0].ks[2]) {
+#define CASE_SZ(S) \
+    case S: return conv_multi_launch<S, 8, 16, 8, 16>(st, B);
         CASE_SZ(7)
         CASE_SZ(9)
         CASE_SZ(11)

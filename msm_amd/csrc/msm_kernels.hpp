@@ -114,6 +114,21 @@ void launch_restrict_axis(hipStream_t st, const double *in, double *out, const i
 // one axis of the separable prolongation: out has the axis doubled; accumulate != 0 adds into out
 void launch_prolong_axis(hipStream_t st, const double *in, double *out, const int Min[3], int axis, int p, const double J[4],
                          int accumulate);
+struct ConvArgs {
+    int M[3], ks[3], kf[3];
+    int z0, nz, accumulate;
+};
+// up to 8 convolutions (levels, or plane ranges of a level) that share one launch
+struct ConvBatch {
+    int n;
+    int blk0[9];
+    int ntx[8], nty[8];
+    ConvArgs c[8];
+    const double *q[8];
+    const double *Kt[8]; // transposed stencils [sy][sx][sz]
+    double *e[8];
+};
+bool launch_conv_multi(hipStream_t st, ConvBatch &B);
 // ---- grid convolution: e[m] = sum_s K[s] q[(m - (first + s)) mod M] for planes [z0, z0+nz) ----
 void launch_conv_direct(hipStream_t st, const double *q, const double *K, const int M[3], const int ksize[3],
                         const int kfirst[3], double *e, int z0, int nz, int accumulate);
