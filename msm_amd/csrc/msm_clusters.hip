@@ -23,7 +23,8 @@ namespace msm {
 // ---------------------------------------------------------------------------
 // sort into columns / fine z bins, cut into clusters, bounding boxes
 // ---------------------------------------------------------------------------
-__global__ void k_cl_count(const double *__restrict__ r, int N, ClusterGeom g, int *__restrict__ bin_of, int *__restrict__ count) {
+__global__ void k_cl_count(const double *__restrict__ r, int N, ClusterGeom g, int *__restrict__ bin_of, int *__restrict__ count,
+                           int *__restrict__ arrival) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     double s[3];
@@ -36,7 +37,7 @@ __global__ void k_cl_count(const double *__restrict__ r, int N, ClusterGeom g, i
     const int zf = min((int)(s[2] * g.nzf), g.nzf - 1);
     const int b = (cy * g.ncx + cx) * g.nzf + zf;
     bin_of[i] = b;
-    atomicAdd(&count[b], 1);
+    arrival[i] = atomicAdd(&count[b], 1);
 }
 
 __global__ void k_cl_colcount(const int *__restrict__ start, ClusterGeom g, int *__restrict__ colncl) {
@@ -100,15 +101,14 @@ __global__ void k_cl_bbox(ClusterGeom g, ClusterBuffers b) {
 }
 
 void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, int N, const ClusterGeom &g,
-                         const ClusterBuffers &b, int *bin_of, int *slot_idx, int *scan_tmp) {
+                         const ClusterBuffers &b, int *bin_of, int *arrival, int *slot_idx, int *scan_tmp) {
     hipMemsetAsync(b.count, 0, sizeof(int) * (size_t)g.nbins, st);
-    hipMemsetAsync(b.fill, 0, sizeof(int) * (size_t)g.nbins, st);
     const int tb = 256, gb = (N + tb - 1) / tb;
-    hipLaunchKernelGGL(k_cl_count, dim3(gb), dim3(tb), 0, st, d_r, N, g, bin_of, b.count);
+    hipLaunchKernelGGL(k_cl_count, dim3(gb), dim3(tb), 0, st, d_r, N, g, bin_of, b.count, arrival);
     launch_exclusive_scan(st, b.count, g.nbins, scan_tmp, b.start);
     hipLaunchKernelGGL(k_cl_colcount, dim3((g.ncols + tb - 1) / tb), dim3(tb), 0, st, b.start, g, b.colncl);
     launch_exclusive_scan(st, b.colncl, g.ncols, scan_tmp, b.clstart);
-    launch_bin_scatter(st, bin_of, N, b.start, b.fill, slot_idx);
+    launch_bin_scatter(st, bin_of, arrival, N, b.start, slot_idx);
     hipLaunchKernelGGL(k_cl_finalize, dim3(gb), dim3(tb), 0, st, d_r, d_q, N, g, bin_of, b.start, b.clstart, slot_idx, b.order,
                        b.ps);
     hipLaunchKernelGGL(k_cl_bbox, dim3((g.max_clusters + tb - 1) / tb), dim3(tb), 0, st, g, b);
@@ -131,20 +131,19 @@ struct ColCursor {
     int cur, end; // clusters [cur, end] of the current segment
 };
 
-__device__ __forceinline__ int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
-
-__device__ __forceinline__ bool cl_column(const ClusterGeom &g, double a2, const IBox &ib, int ex0, int ey0, int nex, int cc,
-                                          ColCursor &c) {
+__device__ __forceinline__ bool cl_column(const ClusterGeom &g, double a2, const IBox &ib, int exi, int eyi, ColCursor &c) {
     const double eps = 1e-6; // slack, in bins, for the different roundings of the sort and of this walk
-    const int exi = ex0 + cc % nex, eyi = ey0 + cc / nex;
     const double gx = fmax(0.0, fmax(ib.lox - (exi + 1 + eps) * g.pitch[0], (exi - eps) * g.pitch[0] - ib.hix));
     const double gy = fmax(0.0, fmax(ib.loy - (eyi + 1 + eps) * g.pitch[1], (eyi - eps) * g.pitch[1] - ib.hiy));
     const double rem = a2 - gx * gx - gy * gy;
     if (rem <= 0.0) return false;
-    const double az = sqrt(rem);
-    const int px = floor_div(exi, g.ncx), py = floor_div(eyi, g.ncy);
-    if (px < -1 || px > 1 || py < -1 || py > 1) return false; // cannot happen while the cell is >= 3 cutoffs wide
-    c.col = (eyi - py * g.ncy) * g.ncx + (exi - px * g.ncx);
+    // reach along z, rounded up (single precision root, widened by more than its error)
+    const double az = (double)(__builtin_amdgcn_sqrtf((float)rem) * 1.00001f);
+    // the cell is at least 3 cutoffs wide, so a column is wrapped by at most one period
+    const int px = exi < 0 ? -1 : (exi >= g.ncx ? 1 : 0), py = eyi < 0 ? -1 : (eyi >= g.ncy ? 1 : 0);
+    const int cx = exi - px * g.ncx, cy = eyi - py * g.ncy;
+    if (cx < 0 || cx >= g.ncx || cy < 0 || cy >= g.ncy) return false;
+    c.col = cy * g.ncx + cx;
     c.sxy = (px + 1) + 3 * (py + 1);
     c.sx = px * g.A[0];
     c.sy = py * g.A[1];
@@ -181,11 +180,13 @@ __device__ __forceinline__ void cl_enumerate(const ClusterGeom &g, const Cluster
     const double eps = 1e-6;
     const int ex0 = (int)floor((ib.lox - a) * g.inv_pitch[0] - eps), ex1 = (int)floor((ib.hix + a) * g.inv_pitch[0] + eps);
     const int ey0 = (int)floor((ib.loy - a) * g.inv_pitch[1] - eps), ey1 = (int)floor((ib.hiy + a) * g.inv_pitch[1] + eps);
-    const int nex = ex1 - ex0 + 1, ntot = nex * (ey1 - ey0 + 1);
-    for (int base = 0; base < ntot; base += 64) {
+    // lanes cover 8 x 8 columns of the extended column grid at a time
+    for (int by = ey0; by <= ey1; by += 8)
+    for (int bx = ex0; bx <= ex1; bx += 8) {
         ColCursor c;
         bool live = false;
-        if (base + lane < ntot && cl_column(g, a2, ib, ex0, ey0, nex, base + lane, c)) live = cl_next_segment(g, b.start, b.clstart, c);
+        const int exi = bx + (lane & 7), eyi = by + (lane >> 3);
+        if (exi <= ex1 && eyi <= ey1 && cl_column(g, a2, ib, exi, eyi, c)) live = cl_next_segment(g, b.start, b.clstart, c);
         while (__ballot(live)) {
             int jcl = 0, code = CL_NOSHIFT;
             bool keep = false;
@@ -267,7 +268,9 @@ __device__ __forceinline__ void cl_slot(double xi, double yi, double zi, const d
         r2 = in ? r2 : pp.a2;
     }
     if (SKIP && !__ballot(in)) return; // no pair of this cluster pair is inside the cutoff
-    const double qm = in ? pj.w : 0.0;
+    // charge of a pair outside the cutoff: high word cleared, i.e. 0 or a denormal below 1e-308 whose products
+    // vanish against any in-range term (one select instead of two)
+    const double qm = __hiloint2double(in ? __double2hiint(pj.w) : 0, __double2loint(pj.w));
     const double ir = rsqrt_seeded(r2);
     const double y = fma(r2, pp.inv_a2, -1.0);
     double gam = pp.cga[P - 1], dg = pp.cda[P - 2];
@@ -333,7 +336,7 @@ __device__ __forceinline__ void shift_of_code(const ClusterGeom &g, int code, do
 }
 
 // One wave per cluster i, lane = (ii, jj) = (lane / 8, lane % 8); walks the list built by k_cl_list.
-template <int P, bool SKIP>
+template <int P, bool SKIP, int U>
 __global__ __launch_bounds__(256) void k_pair_clusters(ClusterGeom g, ClusterBuffers b, PairParams pp, double *__restrict__ acc,
                                                        double *__restrict__ epart) {
     const int lane = threadIdx.x & 63, ii = lane >> 3, jj = lane & 7;
@@ -358,13 +361,12 @@ __global__ __launch_bounds__(256) void k_pair_clusters(ClusterGeom g, ClusterBuf
     double u = 0, fx = 0, fy = 0, fz = 0;
     cl_slot<P, true>(I.x, I.y, I.z, pj[(size_t)CL_G * icl], pp, ii != jj, u, fx, fy, fz);
     int e = 1;
-    for (; e + 4 <= n0; e += 4) {
-        const int j0 = L[e], j1 = L[e + 1], j2 = L[e + 2], j3 = L[e + 3];
-        const double4 q0 = pj[(size_t)CL_G * j0], q1 = pj[(size_t)CL_G * j1], q2 = pj[(size_t)CL_G * j2], q3 = pj[(size_t)CL_G * j3];
-        cl_slot<P, false, SKIP>(I.x, I.y, I.z, q0, pp, true, u, fx, fy, fz);
-        cl_slot<P, false, SKIP>(I.x, I.y, I.z, q1, pp, true, u, fx, fy, fz);
-        cl_slot<P, false, SKIP>(I.x, I.y, I.z, q2, pp, true, u, fx, fy, fz);
-        cl_slot<P, false, SKIP>(I.x, I.y, I.z, q3, pp, true, u, fx, fy, fz);
+    for (; e + U <= n0; e += U) {
+        double4 qv[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) qv[k] = pj[(size_t)CL_G * L[e + k]];
+#pragma unroll
+        for (int k = 0; k < U; k++) cl_slot<P, false, SKIP>(I.x, I.y, I.z, qv[k], pp, true, u, fx, fy, fz);
     }
     for (; e < n0; e++) cl_slot<P, false, SKIP>(I.x, I.y, I.z, pj[(size_t)CL_G * L[e]], pp, true, u, fx, fy, fz);
     for (e = 0; e < n1; e++) {
@@ -430,16 +432,21 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
         return;
     }
     hipLaunchKernelGGL(k_cl_list, dim3(nblk), dim3(256), 0, st, g, b, a, pp.a2);
-    const bool skip = variant == 2;
+#define LAUNCH_PC(P, SKIP, U) hipLaunchKernelGGL((k_pair_clusters<P, SKIP, U>), dim3(nblk), dim3(256), 0, st, g, b, pp, acc, epart)
     if (pp.p == 4) {
-        if (skip) hipLaunchKernelGGL((k_pair_clusters<4, true>), dim3(nblk), dim3(256), 0, st, g, b, pp, acc, epart);
-        else hipLaunchKernelGGL((k_pair_clusters<4, false>), dim3(nblk), dim3(256), 0, st, g, b, pp, acc, epart);
+        if (variant == 2) LAUNCH_PC(4, true, 4);
+        else if (variant == 3) LAUNCH_PC(4, false, 2);
+        else if (variant == 4) LAUNCH_PC(4, false, 8);
+        else LAUNCH_PC(4, false, 4);
         hipLaunchKernelGGL((k_pair_clusters_direct<4, true>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart);
     } else {
-        if (skip) hipLaunchKernelGGL((k_pair_clusters<6, true>), dim3(nblk), dim3(256), 0, st, g, b, pp, acc, epart);
-        else hipLaunchKernelGGL((k_pair_clusters<6, false>), dim3(nblk), dim3(256), 0, st, g, b, pp, acc, epart);
+        if (variant == 2) LAUNCH_PC(6, true, 4);
+        else if (variant == 3) LAUNCH_PC(6, false, 2);
+        else if (variant == 4) LAUNCH_PC(6, false, 8);
+        else LAUNCH_PC(6, false, 4);
         hipLaunchKernelGGL((k_pair_clusters_direct<6, true>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart);
     }
+#undef LAUNCH_PC
 }
 
 } // namespace msm

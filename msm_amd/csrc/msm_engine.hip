@@ -39,7 +39,7 @@ struct msm_amd_handle {
     // particles
     double4 *ps_cell = nullptr, *ps_grid = nullptr;
     int *order_cell = nullptr, *order_grid = nullptr, *bin_of = nullptr, *slot_idx = nullptr;
-    int *ccount = nullptr, *cstart = nullptr, *cfill = nullptr, *gcount = nullptr, *gstart = nullptr, *gfill = nullptr;
+    int *ccount = nullptr, *cstart = nullptr, *gcount = nullptr, *gstart = nullptr, *arrival = nullptr;
     int *scan_tmp = nullptr;
     // grids
     std::vector<double *> gq, ge, dK, dKt;
@@ -205,8 +205,8 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         if (rc) { msm_amd_destroy(h); return rc; } \
     } while (0)
     DA(h->ps_cell, N); DA(h->ps_grid, N); DA(h->order_cell, N); DA(h->order_grid, N); DA(h->bin_of, N); DA(h->slot_idx, N);
-    DA(h->ccount, h->ncell); DA(h->cstart, h->ncell + 1); DA(h->cfill, h->ncell);
-    DA(h->gcount, h->gridg.nbins); DA(h->gstart, h->gridg.nbins + 1); DA(h->gfill, h->gridg.nbins);
+    DA(h->ccount, h->ncell); DA(h->cstart, h->ncell + 1); DA(h->arrival, N);
+    DA(h->gcount, h->gridg.nbins); DA(h->gstart, h->gridg.nbins + 1);
     {
         const int nb = std::max(std::max(h->ncell, h->gridg.nbins), cg.nbins);
         DA(h->scan_tmp, nb / 2048 + 2);
@@ -214,7 +214,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
     if (!h->small_box) {
         ClusterBuffers &cb = h->clb;
         const size_t nslots = (size_t)cg.max_clusters * CL_G;
-        DA(cb.count, cg.nbins); DA(cb.start, cg.nbins + 1); DA(cb.fill, cg.nbins);
+        DA(cb.count, cg.nbins); DA(cb.start, cg.nbins + 1);
         DA(cb.colncl, cg.ncols + 1); DA(cb.clstart, cg.ncols + 1);
         DA(cb.order, nslots); DA(cb.ps, nslots);
         DA(cb.blo, cg.max_clusters); DA(cb.bhi, cg.max_clusters);
@@ -275,11 +275,11 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     hipFree(h->ps_cell); hipFree(h->ps_grid); hipFree(h->order_cell); hipFree(h->order_grid); hipFree(h->bin_of);
-    hipFree(h->slot_idx); hipFree(h->ccount); hipFree(h->cstart); hipFree(h->cfill); hipFree(h->gcount); hipFree(h->gstart);
-    hipFree(h->gfill); hipFree(h->scan_tmp); hipFree(h->tile_scratch);
+    hipFree(h->slot_idx); hipFree(h->ccount); hipFree(h->cstart); hipFree(h->arrival); hipFree(h->gcount); hipFree(h->gstart);
+    hipFree(h->scan_tmp); hipFree(h->tile_scratch);
     {
         ClusterBuffers &cb = h->clb;
-        hipFree(cb.count); hipFree(cb.start); hipFree(cb.fill); hipFree(cb.colncl); hipFree(cb.clstart); hipFree(cb.order);
+        hipFree(cb.count); hipFree(cb.start); hipFree(cb.colncl); hipFree(cb.clstart); hipFree(cb.order);
         hipFree(cb.ps); hipFree(cb.blo); hipFree(cb.bhi); hipFree(cb.list); hipFree(cb.n0); hipFree(cb.n1);
     }
     for (auto p : h->gq) hipFree(p);
@@ -342,15 +342,15 @@ extern "C" int msm_amd_stage_bin(msm_amd_handle *h, const double *d_r, const dou
     h->clusters_sorted = false;
     if (!h->small_box) {
         if (h->opt_pair_variant >= 5 && h->pp.convention != MSM_AMD_ACC_LITERAL) {
-            launch_cluster_sort(h->stream, d_r, d_q, h->N, h->clg, h->clb, h->bin_of, h->slot_idx, h->scan_tmp);
+            launch_cluster_sort(h->stream, d_r, d_q, h->N, h->clg, h->clb, h->bin_of, h->arrival, h->slot_idx, h->scan_tmp);
             h->clusters_sorted = true;
         } else {
-            launch_bin(h->stream, d_r, d_q, h->N, h->cellg, h->bin_of, h->ccount, h->cstart, h->cfill, h->slot_idx, h->scan_tmp,
+            launch_bin(h->stream, d_r, d_q, h->N, h->cellg, h->bin_of, h->ccount, h->cstart, h->arrival, h->slot_idx, h->scan_tmp,
                        h->order_cell, h->ps_cell);
             h->cells_binned = true;
         }
     }
-    launch_bin(h->stream, d_r, d_q, h->N, h->gridg, h->bin_of, h->gcount, h->gstart, h->gfill, h->slot_idx, h->scan_tmp,
+    launch_bin(h->stream, d_r, d_q, h->N, h->gridg, h->bin_of, h->gcount, h->gstart, h->arrival, h->slot_idx, h->scan_tmp,
                h->order_grid, h->ps_grid);
     HIPCHK(hipGetLastError());
     return MSM_AMD_OK;
@@ -366,13 +366,13 @@ extern "C" int msm_amd_stage_pairs(msm_amd_handle *h, double *d_acc) {
         // cluster pairs (5: neighbour lists, 6: list-free); the unweighted sums of the literal convention exist
         // only in the cell kernels
         if (!h->clusters_sorted)
-            launch_cluster_sort(h->stream, h->cur_r, h->cur_q, h->N, h->clg, h->clb, h->bin_of, h->slot_idx, h->scan_tmp);
+            launch_cluster_sort(h->stream, h->cur_r, h->cur_q, h->N, h->clg, h->clb, h->bin_of, h->arrival, h->slot_idx, h->scan_tmp);
         h->clusters_sorted = true;
         launch_pair_clusters(h->stream, h->clg, h->clb, h->pp, d_acc, h->epart, h->opt_pair_variant - 5);
         h->nepart = h->clg.max_clusters;
     } else {
         if (!h->cells_binned)
-            launch_bin(h->stream, h->cur_r, h->cur_q, h->N, h->cellg, h->bin_of, h->ccount, h->cstart, h->cfill, h->slot_idx,
+            launch_bin(h->stream, h->cur_r, h->cur_q, h->N, h->cellg, h->bin_of, h->ccount, h->cstart, h->arrival, h->slot_idx,
                        h->scan_tmp, h->order_cell, h->ps_cell);
         h->cells_binned = true;
         launch_pair_cells(h->stream, h->ps_cell, h->cstart, h->order_cell, h->ncell, h->pp, d_acc, h->epart,

@@ -38,14 +38,15 @@ __device__ __forceinline__ int bin_index(const double s[3], const BinGeom &g) {
     return (b[2] * g.nb[1] + b[1]) * g.nb[0] + b[0];
 }
 
-__global__ void k_bin_count(const double *__restrict__ r, int N, BinGeom g, int *__restrict__ bin_of, int *__restrict__ count) {
+__global__ void k_bin_count(const double *__restrict__ r, int N, BinGeom g, int *__restrict__ bin_of, int *__restrict__ count,
+                            int *__restrict__ arrival) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     double s[3];
     frac_coords(r, i, g, s);
     int b = bin_index(s, g);
     bin_of[i] = b;
-    atomicAdd(&count[b], 1);
+    arrival[i] = atomicAdd(&count[b], 1); // place among the bin's members, in the (arbitrary) order the adds landed
 }
 
 #define SCAN_THREADS 256
@@ -120,13 +121,11 @@ __global__ void k_scan_apply(const int *__restrict__ in, int n, const int *__res
     }
 }
 
-__global__ void k_bin_scatter(const int *__restrict__ bin_of, int N, const int *__restrict__ start, int *__restrict__ fill,
-                              int *__restrict__ slot_idx) {
+__global__ void k_bin_scatter(const int *__restrict__ bin_of, const int *__restrict__ arrival, int N,
+                              const int *__restrict__ start, int *__restrict__ slot_idx) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    int b = bin_of[i];
-    int s = start[b] + atomicAdd(&fill[b], 1);
-    slot_idx[s] = i;
+    slot_idx[start[bin_of[i]] + arrival[i]] = i;
 }
 
 // The scatter above fills a bin in arrival order.  Rank every entry by its particle index inside
@@ -155,20 +154,19 @@ void launch_exclusive_scan(hipStream_t st, const int *in, int n, int *scan_tmp, 
     hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(SCAN_THREADS), 0, st, in, n, scan_tmp, out);
 }
 
-void launch_bin_scatter(hipStream_t st, const int *bin_of, int N, const int *start, int *fill, int *slot_idx) {
+void launch_bin_scatter(hipStream_t st, const int *bin_of, const int *arrival, int N, const int *start, int *slot_idx) {
     const int tb = 256, gb = (N + tb - 1) / tb;
-    hipLaunchKernelGGL(k_bin_scatter, dim3(gb), dim3(tb), 0, st, bin_of, N, start, fill, slot_idx);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(gb), dim3(tb), 0, st, bin_of, arrival, N, start, slot_idx);
 }
 
 void launch_bin(hipStream_t st, const double *d_r, const double *d_q, int N, const BinGeom &g, int *bin_of, int *count,
-                int *start, int *fill, int *slot_idx, int *scan_tmp, int *order, double4 *ps) {
+                int *start, int *arrival, int *slot_idx, int *scan_tmp, int *order, double4 *ps) {
     const int nb = g.nbins;
     hipMemsetAsync(count, 0, sizeof(int) * (size_t)nb, st);
-    hipMemsetAsync(fill, 0, sizeof(int) * (size_t)nb, st);
     const int tb = 256, gb = (N + tb - 1) / tb;
-    hipLaunchKernelGGL(k_bin_count, dim3(gb), dim3(tb), 0, st, d_r, N, g, bin_of, count);
+    hipLaunchKernelGGL(k_bin_count, dim3(gb), dim3(tb), 0, st, d_r, N, g, bin_of, count, arrival);
     launch_exclusive_scan(st, count, nb, scan_tmp, start);
-    launch_bin_scatter(st, bin_of, N, start, fill, slot_idx);
+    launch_bin_scatter(st, bin_of, arrival, N, start, slot_idx);
     hipLaunchKernelGGL(k_bin_finalize, dim3(gb), dim3(tb), 0, st, d_r, d_q, N, g, bin_of, start, slot_idx, order, ps);
 }
 

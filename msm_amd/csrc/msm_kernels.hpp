@@ -60,9 +60,9 @@ struct TileGeom {
 
 // ---- binning ----
 void launch_bin(hipStream_t st, const double *d_r, const double *d_q, int N, const BinGeom &g, int *bin_of, int *count,
-                int *start, int *fill, int *slot_idx, int *scan_tmp, int *order, double4 *ps);
+                int *start, int *arrival, int *slot_idx, int *scan_tmp, int *order, double4 *ps);
 void launch_exclusive_scan(hipStream_t st, const int *in, int n, int *scan_tmp, int *out);
-void launch_bin_scatter(hipStream_t st, const int *bin_of, int N, const int *start, int *fill, int *slot_idx);
+void launch_bin_scatter(hipStream_t st, const int *bin_of, const int *arrival, int N, const int *start, int *slot_idx);
 
 // ---- cluster pairs ----
 // Particles are sorted into columns (x, y) and by z inside a column, then cut into clusters of CL_G consecutive
@@ -80,7 +80,7 @@ struct ClusterGeom {
     double far;          // coordinate given to padding slots
 };
 struct ClusterBuffers {
-    int *count, *start, *fill;  // per fine bin (start has nbins + 1 entries)
+    int *count, *start;         // per fine bin (start has nbins + 1 entries)
     int *colncl, *clstart;      // clusters per column and their exclusive scan (ncols + 1; last = cluster count)
     int *order;                 // original particle index per slot, CL_DUMMY for padding
     double4 *ps;                // (x, y, z, q) per slot, absolute coordinates in [0, A)
@@ -88,7 +88,7 @@ struct ClusterBuffers {
     int *list, *n0, *n1;        // neighbour-cluster lists: n0 unshifted entries from the front, n1 shifted from the back
 };
 void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, int N, const ClusterGeom &g,
-                         const ClusterBuffers &b, int *bin_of, int *slot_idx, int *scan_tmp);
+                         const ClusterBuffers &b, int *bin_of, int *arrival, int *slot_idx, int *scan_tmp);
 // variant 0: build lists, then one wave per cluster walks its list; variant 1: no lists, every wave enumerates and
 // evaluates its candidates directly.  Clusters whose list overflowed list_stride are evaluated by the direct kernel.
 void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double *acc,
