@@ -14,10 +14,12 @@ particles in a periodic unit cube, quintic B-spline (p = 6) unless --order 4, ab
 levels 96 -> 48 -> 24 -> 12 plus the Fourier top level.  N > 1 keeps the total work fixed (strong scaling):
 the same million particles are split into z slabs.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the pair sum): algorithmic flops
-(ordered in-cutoff pairs x 34 flop at p=4 / 42 at p=6) over the kernel's mean duration measured with HIP
-events on the stream the kernel runs on.  `cpu_baseline` is the CPU oracle (a port of the same mathematics,
-oracle/msm_spec.c) timed on this box's host cores on one evaluation of the same system.
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_pair_clusters, the short-range pair
+sum): algorithmic flops (ordered in-cutoff pairs x 34 flop at p=4 / 42 at p=6) over that kernel's mean
+duration, measured with a pair of HIP events recorded around it on the stream it runs on.  `traffic` is the
+HBM-side byte count of one launch from rocprofv3 PMC passes (profiles/r01_pair_traffic.json; null if that
+file is absent).  `cpu_baseline` is the CPU oracle (a port of the same mathematics, oracle/msm_spec.c) timed on
+this box's host cores on one evaluation of the same system; `parity` compares the GPU result with it.
 """
 import argparse
 import json
@@ -95,6 +97,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ref_eval = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        ref_eval = stepper.eval_unperturbed()   # untimed: the same positions the CPU oracle gets
+
     for _ in range(args.warmup):
         stepper.step()
     barrier()
@@ -115,12 +121,25 @@ def main():
 
     pairs = N * (4.0 * math.pi / 3.0) * abar ** 3 / world   # ordered in-cutoff pairs handled by one rank's launch
     flops = pairs * FLOP_PER_PAIR[p]
-    pair_s = acc_ms["pairs"] * 1e-3
+    pair_s = acc_ms.get("pair_kernel", acc_ms["pairs"]) * 1e-3
     achieved = flops / pair_s / 1e12 if pair_s > 0 else 0.0
 
-    cpu = None
+    cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(desc, r_all, q_all)
+        cpu, cpu_out = cpu_baseline(desc, r_all, q_all)
+        en_gpu, acc_gpu = ref_eval
+        en_cpu = cpu_out["energies"]
+        scale = float(np.abs(en_cpu[:6]).max())
+        da = acc_gpu - cpu_out["acc"]
+        parity = {"energy_max_abs_diff_over_largest_component": float(np.abs(en_gpu - en_cpu).max() / scale),
+                  "utotal_gpu": float(en_gpu[6]), "utotal_cpu": float(en_cpu[6]),
+                  "acc_rel_rms_diff": float(np.sqrt((da ** 2).sum() / (cpu_out["acc"] ** 2).sum())),
+                  "tolerance": 1e-12}
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pair_traffic.json")
+    if world == 1 and os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get("order%d" % p, {}).get("hbm_bytes_per_launch")
 
     if rank == 0:
         out = {
@@ -141,9 +160,9 @@ def main():
                                    % (N, p, "x".join(str(m) for m in desc.M), desc.L, desc.kmax),
                        "particles": N, "order": p, "levels": desc.L, "grid": list(desc.M),
                        "parallelism": "single GPU" if world == 1 else "z-slabs x%d, level-0 charge all-gather" % world},
-            "roofline": {"kernel": "k_pair_cells (short-range pair sum)", "bound": "mfma", "achieved": achieved,
+            "roofline": {"kernel": "k_pair_clusters (short-range pair sum)", "bound": "mfma", "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                         "traffic": None,
+                         "traffic": traffic, "kernel_ms": pair_s * 1e3,
                          "note": "FP64 vector FMA bound (the FP64 MFMA peak is the same 78.6 TF); algorithmic flops = "
                                  "N*(4pi/3)*abar^3 ordered pairs x %d flop" % FLOP_PER_PAIR[p]},
             "kernel_ms": acc_ms,
@@ -151,6 +170,7 @@ def main():
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
+            out["parity"] = parity
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
@@ -175,13 +195,22 @@ class SingleGpu:
         self.sign = -self.sign
         self.last_energies, _ = self.eng.eval(self.r, self.q, self.acc)
 
+    def eval_unperturbed(self):
+        en, acc = self.eng.eval(self.r, self.q, self.acc)
+        return np.array(en), acc.cpu().numpy().copy()
+
     def profile(self, n):
-        # the engine brackets every stage with hipEventRecord on its own stream
+        # the engine brackets every stage, and the pair kernel by itself, with hipEventRecord on its own stream
         self.eng.set_profiling(True)
         acc = {}
         for _ in range(n):
             self.step()
-            for k, v in self.eng.last_timings().items():
+            t = dict(self.eng.last_timings())
+            try:
+                t["pair_kernel"] = self.eng.last_kernel_ms("pair_kernel")
+            except Exception:
+                pass
+            for k, v in t.items():
                 acc[k] = acc.get(k, 0.0) + v / n
         self.eng.set_profiling(False)
         return acc
@@ -224,7 +253,7 @@ def cpu_baseline(desc, r, q):
     return {"value": 1.0 / dt, "unit": "evals/s", "cores": cores, "kind": "port",
             "sample": "1 evaluation of the same %d-particle system (all stages)" % desc.N,
             "stage_seconds": dict(zip(names, [float(x) for x in out["seconds"]])),
-            "utotal": float(out["energies"][6])}
+            "utotal": float(out["energies"][6])}, out
 
 
 if __name__ == "__main__":

@@ -250,6 +250,10 @@ int msm_amd_op_convolve(msm_amd_handle *h, int level, const double *d_q, double 
 /* per-kernel wall time of the last msm_amd_eval in milliseconds (HIP events on the handle's stream):
  * [bin, pairs, anterpolation, restriction, convolution, top, prolongation, interpolation, reductions, total] */
 int msm_amd_last_timings(msm_amd_handle *h, double ms[10]);
+/* duration in milliseconds of one named kernel inside the last profiled msm_amd_eval, bracketed by its own pair
+ * of HIP events: "pair_kernel" (the cluster-pair kernel alone, without the sort and the list build that the
+ * "pairs" stage above includes).  MSM_AMD_EINVAL for an unknown name or when that kernel did not run. */
+int msm_amd_last_kernel_ms(msm_amd_handle *h, const char *name, double *ms);
 /* enable per-stage event timing (adds event records to the stream); off by default */
 void msm_amd_set_profiling(msm_amd_handle *h, int on);
 /* select kernel variants (for A/B benchmarking); key/value, returns MSM_AMD_EINVAL for unknown keys */

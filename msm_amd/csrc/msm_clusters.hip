@@ -98,6 +98,8 @@ __global__ void k_cl_bbox(ClusterGeom g, ClusterBuffers b) {
     }
     b.blo[k] = make_double4(l[0], l[1], l[2], 0.0);
     b.bhi[k] = make_double4(h[0], h[1], h[2], 0.0);
+    b.fbox[2 * (size_t)k] = make_float4(__double2float_rd(l[0]), __double2float_rd(l[1]), __double2float_rd(l[2]), 0.f);
+    b.fbox[2 * (size_t)k + 1] = make_float4(__double2float_ru(h[0]), __double2float_ru(h[1]), __double2float_ru(h[2]), 0.f);
 }
 
 void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, int N, const ClusterGeom &g,
@@ -125,7 +127,7 @@ struct IBox {
 struct ColCursor {
     int col;      // wrapped column index
     int sxy;      // (px+1) + 3 (py+1): periods the column was wrapped by
-    double sx, sy;
+    float ilx, ihx, ily, ihy; // the i box along x and y, shifted back by the column's image shift
     int zf0, zf1; // extended fine-bin range to visit
     int k;        // current z period (-1, 0, 1); -2 before the first segment
     int cur, end; // clusters [cur, end] of the current segment
@@ -145,8 +147,9 @@ __device__ __forceinline__ bool cl_column(const ClusterGeom &g, double a2, const
     if (cx < 0 || cx >= g.ncx || cy < 0 || cy >= g.ncy) return false;
     c.col = cy * g.ncx + cx;
     c.sxy = (px + 1) + 3 * (py + 1);
-    c.sx = px * g.A[0];
-    c.sy = py * g.A[1];
+    const float sx = (float)(px * g.A[0]), sy = (float)(py * g.A[1]);
+    c.ilx = __double2float_rd(ib.lox) - sx; c.ihx = __double2float_ru(ib.hix) - sx;
+    c.ily = __double2float_rd(ib.loy) - sy; c.ihy = __double2float_ru(ib.hiy) - sy;
     c.zf0 = (int)floor((ib.loz - az) * g.inv_dzf - eps);
     c.zf1 = (int)floor((ib.hiz + az) * g.inv_dzf + eps);
     c.k = -2;
@@ -180,6 +183,7 @@ __device__ __forceinline__ void cl_enumerate(const ClusterGeom &g, const Cluster
     const double eps = 1e-6;
     const int ex0 = (int)floor((ib.lox - a) * g.inv_pitch[0] - eps), ex1 = (int)floor((ib.hix + a) * g.inv_pitch[0] + eps);
     const int ey0 = (int)floor((ib.loy - a) * g.inv_pitch[1] - eps), ey1 = (int)floor((ib.hiy + a) * g.inv_pitch[1] + eps);
+    const float ilz = __double2float_rd(ib.loz), ihz = __double2float_ru(ib.hiz);
     // lanes cover 8 x 8 columns of the extended column grid at a time
     for (int by = ey0; by <= ey1; by += 8)
     for (int bx = ex0; bx <= ex1; bx += 8) {
@@ -193,12 +197,14 @@ __device__ __forceinline__ void cl_enumerate(const ClusterGeom &g, const Cluster
             if (live) {
                 jcl = c.cur;
                 code = c.sxy + 9 * (c.k + 1);
-                const double sz = c.k * g.A[2];
-                const double4 jl = b.blo[jcl], jh = b.bhi[jcl];
-                const double gx = fmax(0.0, fmax(jl.x + c.sx - ib.hix, ib.lox - (jh.x + c.sx)));
-                const double gy = fmax(0.0, fmax(jl.y + c.sy - ib.hiy, ib.loy - (jh.y + c.sy)));
-                const double gz = fmax(0.0, fmax(jl.z + sz - ib.hiz, ib.loz - (jh.z + sz)));
-                keep = gx * gx + gy * gy + gz * gz < a2;
+                // single-precision boxes against the single-precision i box shifted back by the image shift;
+                // the widened cutoff keeps the test conservative
+                const float4 jl = b.fbox[2 * (size_t)jcl], jh = b.fbox[2 * (size_t)jcl + 1];
+                const float szf = (float)(c.k * g.A[2]);
+                const float gx = fmaxf(0.f, fmaxf(jl.x - c.ihx, c.ilx - jh.x));
+                const float gy = fmaxf(0.f, fmaxf(jl.y - c.ihy, c.ily - jh.y));
+                const float gz = fmaxf(0.f, fmaxf(jl.z - (ihz - szf), (ilz - szf) - jh.z));
+                keep = gx * gx + gy * gy + gz * gz < g.a2_wide;
             }
             emit(keep, jcl, code);
             if (live && ++c.cur > c.end) live = cl_next_segment(g, b.start, b.clstart, c);
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(256) void k_pair_clusters_direct(ClusterGeom g, Clu
 }
 
 void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double *acc,
-                          double *epart, int variant) {
+                          double *epart, int variant, hipEvent_t *ev) {
     const double a = sqrt(pp.a2);
     const int nblk = (g.max_clusters + 3) / 4;
     if (variant == 1) {
@@ -432,7 +438,12 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
         return;
     }
     hipLaunchKernelGGL(k_cl_list, dim3(nblk), dim3(256), 0, st, g, b, a, pp.a2);
-#define LAUNCH_PC(P, SKIP, U) hipLaunchKernelGGL((k_pair_clusters<P, SKIP, U>), dim3(nblk), dim3(256), 0, st, g, b, pp, acc, epart)
+#define LAUNCH_PC(P, SKIP, U)                                                                                  \
+    do {                                                                                                       \
+        if (ev) hipEventRecord(ev[0], st);                                                                     \
+        hipLaunchKernelGGL((k_pair_clusters<P, SKIP, U>), dim3(nblk), dim3(256), 0, st, g, b, pp, acc, epart); \
+        if (ev) hipEventRecord(ev[1], st);                                                                     \
+    } while (0)
     if (pp.p == 4) {
         if (variant == 2) LAUNCH_PC(4, true, 4);
         else if (variant == 3) LAUNCH_PC(4, false, 2);

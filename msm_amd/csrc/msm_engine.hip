@@ -55,6 +55,9 @@ struct msm_amd_handle {
     // profiling
     bool profiling = false;
     hipEvent_t ev[T_COUNT + 1];
+    hipEvent_t ev_pk[2];      // around the cluster-pair kernel alone
+    bool pk_recorded = false;
+    double pair_kernel_ms = -1.0;
     bool ev_made = false;
     double last_ms[T_COUNT];
     int opt_pair_variant = 5, opt_conv_tiled = 2, opt_conv_small = 1; // conv_tiled: 0 off, 1 per level, 2 levels share a launch
@@ -197,6 +200,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         cg.inv_pitch[0] = cg.ncx / d.A[0]; cg.inv_pitch[1] = cg.ncy / d.A[1];
         cg.dzf = d.A[2] / cg.nzf; cg.inv_dzf = cg.nzf / d.A[2];
         cg.far = -1.0e3 * amax;
+        { const double aw = d.a + 4e-6 * amax; cg.a2_wide = (float)(aw * aw * (1.0 + 1e-6)); }
     }
 
 #define DA(ptr, n)                      \
@@ -217,7 +221,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         DA(cb.count, cg.nbins); DA(cb.start, cg.nbins + 1);
         DA(cb.colncl, cg.ncols + 1); DA(cb.clstart, cg.ncols + 1);
         DA(cb.order, nslots); DA(cb.ps, nslots);
-        DA(cb.blo, cg.max_clusters); DA(cb.bhi, cg.max_clusters);
+        DA(cb.blo, cg.max_clusters); DA(cb.bhi, cg.max_clusters); DA(cb.fbox, 2 * (size_t)cg.max_clusters);
         DA(cb.list, (size_t)cg.max_clusters * cg.list_stride); DA(cb.n0, cg.max_clusters); DA(cb.n1, cg.max_clusters);
     }
     h->gq.assign(L, nullptr); h->ge.assign(L, nullptr); h->dK.assign(L, nullptr); h->dKt.assign(L, nullptr);
@@ -280,7 +284,7 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     {
         ClusterBuffers &cb = h->clb;
         hipFree(cb.count); hipFree(cb.start); hipFree(cb.colncl); hipFree(cb.clstart); hipFree(cb.order);
-        hipFree(cb.ps); hipFree(cb.blo); hipFree(cb.bhi); hipFree(cb.list); hipFree(cb.n0); hipFree(cb.n1);
+        hipFree(cb.ps); hipFree(cb.blo); hipFree(cb.bhi); hipFree(cb.fbox); hipFree(cb.list); hipFree(cb.n0); hipFree(cb.n1);
     }
     for (auto p : h->gq) hipFree(p);
     for (auto p : h->ge) hipFree(p);
@@ -290,7 +294,7 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     hipFree(h->d_energies);
     if (h->h_energies) hipHostFree(h->h_energies);
     hipFree(h->s_r); hipFree(h->s_q); hipFree(h->s_acc);
-    if (h->ev_made) for (int i = 0; i <= T_COUNT; i++) hipEventDestroy(h->ev[i]);
+    if (h->ev_made) { for (int i = 0; i <= T_COUNT; i++) hipEventDestroy(h->ev[i]); hipEventDestroy(h->ev_pk[0]); hipEventDestroy(h->ev_pk[1]); }
     delete h;
 }
 
@@ -314,6 +318,7 @@ extern "C" void msm_amd_set_profiling(msm_amd_handle *h, int on) {
     hipSetDevice(h->device);
     if (on && !h->ev_made) {
         for (int i = 0; i <= T_COUNT; i++) hipEventCreate(&h->ev[i]);
+        hipEventCreate(&h->ev_pk[0]); hipEventCreate(&h->ev_pk[1]);
         h->ev_made = true;
     }
     h->profiling = on != 0;
@@ -368,7 +373,9 @@ extern "C" int msm_amd_stage_pairs(msm_amd_handle *h, double *d_acc) {
         if (!h->clusters_sorted)
             launch_cluster_sort(h->stream, h->cur_r, h->cur_q, h->N, h->clg, h->clb, h->bin_of, h->arrival, h->slot_idx, h->scan_tmp);
         h->clusters_sorted = true;
-        launch_pair_clusters(h->stream, h->clg, h->clb, h->pp, d_acc, h->epart, h->opt_pair_variant - 5);
+        launch_pair_clusters(h->stream, h->clg, h->clb, h->pp, d_acc, h->epart, h->opt_pair_variant - 5,
+                             h->profiling ? h->ev_pk : nullptr);
+        h->pk_recorded = h->profiling && h->opt_pair_variant != 6;
         h->nepart = h->clg.max_clusters;
     } else {
         if (!h->cells_binned)
@@ -583,6 +590,7 @@ extern "C" int msm_amd_eval(msm_amd_handle *h, const double *d_r, const double *
     if (!h || !d_r || !d_q || !d_acc) { set_error("msm_amd_eval: null argument"); return MSM_AMD_EINVAL; }
     HIPCHK(hipSetDevice(h->device));
     int rc;
+    h->pk_recorded = false;
     mark(h, T_BIN);
     if ((rc = msm_amd_stage_bin(h, d_r, d_q))) return rc;
     mark(h, T_PAIR);
@@ -610,6 +618,8 @@ extern "C" int msm_amd_eval(msm_amd_handle *h, const double *d_r, const double *
         float ms = 0;
         hipEventElapsedTime(&ms, h->ev[T_BIN], h->ev[T_TOTAL]);
         h->last_ms[T_TOTAL] = ms;
+        h->pair_kernel_ms = -1.0;
+        if (h->pk_recorded && hipEventElapsedTime(&ms, h->ev_pk[0], h->ev_pk[1]) == hipSuccess) h->pair_kernel_ms = ms;
     }
     return MSM_AMD_OK;
 }
@@ -618,6 +628,13 @@ extern "C" int msm_amd_last_timings(msm_amd_handle *h, double ms[10]) {
     if (!h || !ms) return MSM_AMD_EINVAL;
     for (int i = 0; i < T_COUNT; i++) ms[i] = h->last_ms[i];
     return MSM_AMD_OK;
+}
+
+extern "C" int msm_amd_last_kernel_ms(msm_amd_handle *h, const char *name, double *ms) {
+    if (!h || !name || !ms) return MSM_AMD_EINVAL;
+    if (!strcmp(name, "pair_kernel") && h->pair_kernel_ms >= 0.0) { *ms = h->pair_kernel_ms; return MSM_AMD_OK; }
+    set_error("last_kernel_ms: no timing for %s in the last profiled evaluation", name);
+    return MSM_AMD_EINVAL;
 }
 
 static int ensure_staging(msm_amd_handle *h) {

@@ -78,6 +78,7 @@ struct ClusterGeom {
     double pitch[2];
     double inv_dzf, dzf; // fine bins per unit length in z
     double far;          // coordinate given to padding slots
+    float a2_wide;       // cutoff^2 widened to cover single-precision rounding in the box tests
 };
 struct ClusterBuffers {
     int *count, *start;         // per fine bin (start has nbins + 1 entries)
@@ -85,14 +86,16 @@ struct ClusterBuffers {
     int *order;                 // original particle index per slot, CL_DUMMY for padding
     double4 *ps;                // (x, y, z, q) per slot, absolute coordinates in [0, A)
     double4 *blo, *bhi;         // cluster bounding boxes
+    float4 *fbox;               // the same rounded outwards to single precision: [2k] = low corner, [2k+1] = high corner
     int *list, *n0, *n1;        // neighbour-cluster lists: n0 unshifted entries from the front, n1 shifted from the back
 };
 void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, int N, const ClusterGeom &g,
                          const ClusterBuffers &b, int *bin_of, int *arrival, int *slot_idx, int *scan_tmp);
 // variant 0: build lists, then one wave per cluster walks its list; variant 1: no lists, every wave enumerates and
 // evaluates its candidates directly.  Clusters whose list overflowed list_stride are evaluated by the direct kernel.
+// ev (optional): two events recorded immediately before and after the list-walking kernel
 void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double *acc,
-                          double *epart, int variant);
+                          double *epart, int variant, hipEvent_t *ev);
 
 // ---- short range ----
 void launch_pair_cells(hipStream_t st, const double4 *ps, const int *cstart, const int *order, int ncell,

@@ -232,6 +232,11 @@ class Engine:
     def set_option(self, key, value):
         check(load().msm_amd_set_option(self._h, key.encode(), int(value)), "set_option")
 
+    def last_kernel_ms(self, name):
+        ms = C.c_double()
+        check(load().msm_amd_last_kernel_ms(self._h, name.encode(), C.byref(ms)), "last_kernel_ms")
+        return ms.value
+
     def last_timings(self):
         ms = np.zeros(10)
         check(load().msm_amd_last_timings(self._h, ms.ctypes.data_as(_dp)), "last_timings")
