@@ -253,10 +253,10 @@ __global__ __launch_bounds__(256) void k_cl_list(ClusterGeom g, ClusterBuffers b
 // ---------------------------------------------------------------------------
 // pair arithmetic
 // ---------------------------------------------------------------------------
-// 1/sqrt(x) to double precision: single-precision hardware seed (relative error < 2^-21 after the
-// conversions) and one third-order correction, error ~ (5/16) e^3.
+// 1/sqrt(x) to double precision: hardware seed (v_rsq_f64, good to better than 2^-20) and one third-order
+// correction, error ~ (5/16) e^3.
 __device__ __forceinline__ double rsqrt_seeded(double x) {
-    const double y0 = (double)__builtin_amdgcn_rsqf((float)x);
+    const double y0 = __builtin_amdgcn_rsq(x);
     const double e = fma(-x * y0, y0, 1.0);
     return fma(y0 * e, fma(e, 0.375, 0.5), y0);
 }
@@ -278,12 +278,12 @@ __device__ __forceinline__ void cl_slot(double xi, double yi, double zi, const d
     // vanish against any in-range term (one select instead of two)
     const double qm = __hiloint2double(in ? __double2hiint(pj.w) : 0, __double2loint(pj.w));
     const double ir = rsqrt_seeded(r2);
-    const double y = fma(r2, pp.inv_a2, -1.0);
-    double gam = pp.cga[P - 1], dg = pp.cda[P - 2];
+    // gamma(r/a)/a and -gamma'(r/a)/(r a^2) as polynomials in r^2 itself
+    double gam = pp.cgr[P - 1], dg = pp.cdr[P - 2];
 #pragma unroll
-    for (int k = P - 2; k >= 0; k--) gam = fma(gam, y, pp.cga[k]);
+    for (int k = P - 2; k >= 0; k--) gam = fma(gam, r2, pp.cgr[k]);
 #pragma unroll
-    for (int k = P - 3; k >= 0; k--) dg = fma(dg, y, pp.cda[k]);
+    for (int k = P - 3; k >= 0; k--) dg = fma(dg, r2, pp.cdr[k]);
     const double g0 = ir - gam;
     const double s = fma(-(ir * ir), ir, dg);
     u = fma(qm, g0, u);

@@ -157,6 +157,22 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
     pp.inv_a3 = 1.0 / (d.a * d.a * d.a);
     gamma_poly(d.p, pp.cg, pp.cd);
     for (int k = 0; k < 8; k++) { pp.cga[k] = pp.cg[k] * pp.inv_a; pp.cda[k] = pp.cd[k] * pp.inv_a3; }
+    {   // sum_k c_k (t - 1)^k = sum_n t^n sum_{k>=n} c_k C(k,n) (-1)^(k-n), t = r^2 / a^2
+        auto expand = [&](const double *c, int deg, double scale, double *out) {
+            for (int n = 0; n < 8; n++) out[n] = 0.0;
+            for (int n = 0; n <= deg; n++) {
+                long double s = 0.0L;
+                for (int k = n; k <= deg; k++) {
+                    long double b = 1.0L;
+                    for (int i = 1; i <= n; i++) b = b * (k - n + i) / i;
+                    s += (long double)c[k] * b * (((k - n) & 1) ? -1.0L : 1.0L);
+                }
+                out[n] = (double)(s * (long double)scale * powl((long double)pp.inv_a2, n));
+            }
+        };
+        expand(pp.cg, d.p - 1, pp.inv_a, pp.cgr);
+        expand(pp.cd, d.p - 2, pp.inv_a3, pp.cdr);
+    }
     pp.p = d.p;
     pp.convention = d.acc_convention;
     pp.n_owned = h->n_owned;

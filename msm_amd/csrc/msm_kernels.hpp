@@ -26,6 +26,8 @@ struct PairParams {
     double cd[8];    // -gamma'(rho)/rho = sum cd[k] y^k
     double cga[8];   // cg / a   (gamma(rho)/a as a polynomial in y)
     double cda[8];   // cd / a^3
+    double cgr[8];   // gamma(r/a)/a          = sum cgr[n] (r^2)^n  (cga re-expanded in r^2)
+    double cdr[8];   // -gamma'(r/a)/(r a^2)  = sum cdr[n] (r^2)^n
     int p;
     int convention;  // MSM_AMD_ACC_*
     int n_owned;     // particles with original index >= n_owned are halo copies: no output for them
