@@ -23,6 +23,13 @@ namespace msm {
 // ---------------------------------------------------------------------------
 // sort into columns / fine z bins, cut into clusters, bounding boxes
 // ---------------------------------------------------------------------------
+// Column number of column (cx, cy): tiles of 8 x 8 columns, tile after tile.  Clusters are numbered in column
+// order and waves take clusters in that order, so the waves in flight at any time work on a compact patch of
+// columns and find their neighbours' particles in L2 instead of fetching them once per row of columns.
+__device__ __forceinline__ int cl_col(const ClusterGeom &g, int cx, int cy) {
+    return (((cy >> 3) * g.ntx + (cx >> 3)) << 6) + ((cy & 7) << 3) + (cx & 7);
+}
+
 __global__ void k_cl_count(const double *__restrict__ r, int N, ClusterGeom g, int *__restrict__ bin_of, int *__restrict__ count,
                            int *__restrict__ arrival) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -35,7 +42,7 @@ __global__ void k_cl_count(const double *__restrict__ r, int N, ClusterGeom g, i
     }
     const int cx = min((int)(s[0] * g.ncx), g.ncx - 1), cy = min((int)(s[1] * g.ncy), g.ncy - 1);
     const int zf = min((int)(s[2] * g.nzf), g.nzf - 1);
-    const int b = (cy * g.ncx + cx) * g.nzf + zf;
+    const int b = cl_col(g, cx, cy) * g.nzf + zf;
     bin_of[i] = b;
     arrival[i] = atomicAdd(&count[b], 1);
 }
@@ -145,7 +152,7 @@ __device__ __forceinline__ bool cl_column(const ClusterGeom &g, double a2, const
     const int px = exi < 0 ? -1 : (exi >= g.ncx ? 1 : 0), py = eyi < 0 ? -1 : (eyi >= g.ncy ? 1 : 0);
     const int cx = exi - px * g.ncx, cy = eyi - py * g.ncy;
     if (cx < 0 || cx >= g.ncx || cy < 0 || cy >= g.ncy) return false;
-    c.col = cy * g.ncx + cx;
+    c.col = cl_col(g, cx, cy);
     c.sxy = (px + 1) + 3 * (py + 1);
     const float sx = (float)(px * g.A[0]), sy = (float)(py * g.A[1]);
     c.ilx = __double2float_rd(ib.lox) - sx; c.ihx = __double2float_ru(ib.hix) - sx;

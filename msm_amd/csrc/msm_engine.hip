@@ -203,7 +203,8 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         const double c = std::cbrt(CL_G * vol / std::max(N, 1));
         cg.ncx = std::max(1, (int)std::floor(d.A[0] / c + 0.5));
         cg.ncy = std::max(1, (int)std::floor(d.A[1] / c + 0.5));
-        cg.ncols = cg.ncx * cg.ncy;
+        cg.ntx = (cg.ncx + 7) / 8;
+        cg.ncols = cg.ntx * ((cg.ncy + 7) / 8) * 64;
         long nzf = std::max(1L, (long)std::floor(8.0 * d.A[2] / c + 0.5));
         nzf = std::min(nzf, std::max(1L, (4L * N + 1024) / cg.ncols));
         cg.nzf = (int)nzf;

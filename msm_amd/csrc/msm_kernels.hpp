@@ -72,7 +72,8 @@ void launch_bin_scatter(hipStream_t st, const int *bin_of, const int *arrival, i
 #define CL_G 8
 struct ClusterGeom {
     int ncx, ncy, nzf;   // columns along x and y, fine z bins per column
-    int ncols, nbins;    // ncx*ncy, ncols*nzf
+    int ntx;             // column tiles along x: columns are numbered tile by tile (8 x 8 columns per tile), see cl_col()
+    int ncols, nbins;    // column numbers in use (whole tiles, some columns empty), ncols*nzf
     int max_clusters;    // capacity of the per-cluster arrays: ceil(N/CL_G) + ncols
     int list_stride;     // list entries reserved per cluster
     double invA[3], A[3];
