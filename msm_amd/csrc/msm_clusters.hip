@@ -226,11 +226,16 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {
 // One wave per cluster: the list of its neighbour clusters.  Entry 0 is the cluster itself; unshifted
 // neighbours follow from the front, neighbours seen through a periodic image are stored from the back with
 // their shift code in the top bits.
-__global__ __launch_bounds__(256) void k_cl_list(ClusterGeom g, ClusterBuffers b, double a, double a2) {
+__global__ __launch_bounds__(256) void k_cl_list(ClusterGeom g, ClusterBuffers b, double a, double a2, int n_owned) {
     const int lane = threadIdx.x & 63;
     const int icl = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int ncl = b.clstart[g.ncols];
     if (icl >= ncl) return;
+    // a cluster of halo copies only produces no output: no list needed (the pair kernels skip it the same way)
+    if (!__ballot(lane < CL_G && b.order[(size_t)CL_G * icl + lane] < n_owned)) {
+        if (lane == 0) { b.n0[icl] = 0; b.n1[icl] = 0; }
+        return;
+    }
     const double4 il = b.blo[icl], ih = b.bhi[icl];
     const IBox ib = {il.x, il.y, il.z, ih.x, ih.y, ih.z};
     const int S = g.list_stride;
@@ -444,7 +449,7 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
         else hipLaunchKernelGGL((k_pair_clusters_direct<6, false>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart);
         return;
     }
-    hipLaunchKernelGGL(k_cl_list, dim3(nblk), dim3(256), 0, st, g, b, a, pp.a2);
+    hipLaunchKernelGGL(k_cl_list, dim3(nblk), dim3(256), 0, st, g, b, a, pp.a2, pp.n_owned);
 #define LAUNCH_PC(P, SKIP, U)                                                                                  \
     do {                                                                                                       \
         if (ev) hipEventRecord(ev[0], st);                                                                     \

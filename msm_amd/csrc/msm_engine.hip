@@ -68,6 +68,7 @@ struct msm_amd_handle {
     // LDS-tiled anterpolation
     TileGeom tiles = {};
     double *tile_scratch = nullptr;
+    int *tile_used = nullptr;
     bool anterp_tiled = false;
     int opt_anterp_tiled = 1;
 };
@@ -271,6 +272,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         h->tiles.ntiles = h->tiles.nt[0] * h->tiles.nt[1] * h->tiles.nt[2];
         const int R = SPLINE_TILE + d.p - 1;
         DA(h->tile_scratch, (size_t)h->tiles.ntiles * R * R * R);
+        DA(h->tile_used, h->tiles.ntiles);
     }
     h->nepart = h->small_box ? (N + 63) / 64 : h->ncell;
     DA(h->epart, std::max(h->nepart, cg.max_clusters));
@@ -297,7 +299,7 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     hipStreamSynchronize(h->stream);
     hipFree(h->ps_cell); hipFree(h->ps_grid); hipFree(h->order_cell); hipFree(h->order_grid); hipFree(h->bin_of);
     hipFree(h->slot_idx); hipFree(h->ccount); hipFree(h->cstart); hipFree(h->arrival); hipFree(h->gcount); hipFree(h->gstart);
-    hipFree(h->scan_tmp); hipFree(h->tile_scratch);
+    hipFree(h->scan_tmp); hipFree(h->tile_scratch); hipFree(h->tile_used);
     {
         ClusterBuffers &cb = h->clb;
         hipFree(cb.count); hipFree(cb.start); hipFree(cb.colncl); hipFree(cb.clstart); hipFree(cb.order);
@@ -410,7 +412,7 @@ extern "C" int msm_amd_stage_pairs(msm_amd_handle *h, double *d_acc) {
 extern "C" int msm_amd_stage_anterpolate(msm_amd_handle *h) {
     if (!h || !h->cur_r) { set_error("stage_anterpolate: bin first"); return MSM_AMD_EINVAL; }
     if (!(h->anterp_tiled && h->opt_anterp_tiled &&
-          launch_anterp_tiled(h->stream, h->ps_grid, h->gstart, h->sp, h->tiles, h->tile_scratch, h->gq[0])))
+          launch_anterp_tiled(h->stream, h->ps_grid, h->gstart, h->sp, h->tiles, h->tile_scratch, h->tile_used, h->gq[0])))
         launch_anterp(h->stream, h->ps_grid, h->gstart, h->sp, h->gq[0]);
     HIPCHK(hipGetLastError());
     return MSM_AMD_OK;
@@ -482,7 +484,7 @@ extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
             const Range &r = ranges[i];
             const LevelStencil &S = h->hp.K[r.l];
             const int *M = h->hp.Ml[r.l];
-            if (!(M[0] >= 16 && M[1] >= 8 && r.nz >= 8)) continue;
+            if (!(M[0] >= 16 && M[1] >= 8 && M[2] >= 8)) continue; // a short plane range of a large grid is fine
             if (B.n > 0 && S.size[2] != B.c[0].ks[2]) continue;
             ConvArgs &c = B.c[B.n];
             for (int k = 0; k < 3; k++) { c.M[k] = M[k]; c.ks[k] = S.size[k]; c.kf[k] = S.first[k]; }

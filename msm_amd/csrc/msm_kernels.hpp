@@ -110,7 +110,7 @@ void launch_anterp(hipStream_t st, const double4 *ps_grid, const int *gstart, co
 // LDS-tiled form; scratch holds ntiles * (SPLINE_TILE + p - 1)^3 doubles.  Needs M >= 24 on every axis and the
 // plain index convention (no node_shift / drop_last).
 bool launch_anterp_tiled(hipStream_t st, const double4 *ps_grid, const int *gstart, const SplineParams &sp, const TileGeom &tl,
-                         double *scratch, double *grid);
+                         double *scratch, int *tile_used, double *grid);
 void launch_interp_tiled(hipStream_t st, const double4 *ps_grid, const int *order, const int *gstart, const SplineParams &sp,
                          const TileGeom &tl, const double *egrid, double *acc);
 void launch_interp(hipStream_t st, const double4 *ps_grid, const int *order, int N, const SplineParams &sp,

@@ -32,18 +32,30 @@ __device__ __forceinline__ double piece_eval(const double *c, double f) {
 
 template <int P>
 __global__ __launch_bounds__(256) void k_anterp_tiles(const double4 *__restrict__ ps, const int *__restrict__ gstart,
-                                                      SplineParams sp, TileGeom tl, double *__restrict__ scratch) {
+                                                      SplineParams sp, TileGeom tl, double *__restrict__ scratch,
+                                                      int *__restrict__ tile_used) {
     constexpr int R = AT + P - 1, R3 = R * R * R;
     extern __shared__ double lds[]; // 4 copies of the node block
+    __shared__ int any_particle;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *__restrict__ mine = lds + wave * R3;
-    for (int t = threadIdx.x; t < 4 * R3; t += 256) lds[t] = 0.0;
-    __syncthreads();
     const int tile = blockIdx.x;
     const int tx = tile % tl.nt[0], ty = (tile / tl.nt[0]) % tl.nt[1], tz = tile / (tl.nt[0] * tl.nt[1]);
     const int Mx = sp.M[0], My = sp.M[1], Mz = sp.M[2];
     const int x0 = tx * AT, y0 = ty * AT, z0 = tz * AT;
     const int nxc = min(AT, Mx - x0), nyc = min(AT, My - y0), nzc = min(AT, Mz - z0);
+    // an empty tile (most tiles of a slab rank) is only flagged; the combine kernel then skips its block
+    if (threadIdx.x == 0) any_particle = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < nyc * nzc) {
+        const int b0 = ((z0 + (int)threadIdx.x / nyc) * My + (y0 + (int)threadIdx.x % nyc)) * Mx + x0;
+        if (gstart[b0 + nxc] > gstart[b0]) any_particle = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) tile_used[tile] = any_particle;
+    if (!any_particle) return;
+    for (int t = threadIdx.x; t < 4 * R3; t += 256) lds[t] = 0.0;
+    __syncthreads();
     // the nodes this lane adds to, relative to the first node of a particle's support
     const int a = P == 4 ? (lane & 3) : lane % 6, b = P == 4 ? ((lane >> 2) & 3) : (lane / 6) % 6, c = P == 4 ? (lane >> 4) : 0;
     const bool active = P == 4 || lane < 36;
@@ -109,8 +121,8 @@ __device__ __forceinline__ int axis_sources(int x, int M, int *ti, int *li) {
 }
 
 template <int P>
-__global__ __launch_bounds__(256) void k_anterp_combine(const double *__restrict__ scratch, SplineParams sp, TileGeom tl,
-                                                        double *__restrict__ grid) {
+__global__ __launch_bounds__(256) void k_anterp_combine(const double *__restrict__ scratch, const int *__restrict__ tile_used,
+                                                        SplineParams sp, TileGeom tl, double *__restrict__ grid) {
     constexpr int R = AT + P - 1, R3 = R * R * R;
     const int Mx = sp.M[0], My = sp.M[1];
     const size_t nplane = (size_t)Mx * My;
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(256) void k_anterp_combine(const double *__restrict
         for (int ky = 0; ky < ny; ky++)
             for (int kx = 0; kx < nx; kx++) {
                 const size_t t = ((size_t)tiz[kz] * tl.nt[1] + tiy[ky]) * tl.nt[0] + tix[kx];
-                sum += scratch[t * R3 + (liz[kz] * R + liy[ky]) * R + lix[kx]];
+                if (tile_used[t]) sum += scratch[t * R3 + (liz[kz] * R + liy[ky]) * R + lix[kx]];
             }
     grid[((size_t)jz * My + jy) * Mx + jx] = sum;
 }
@@ -236,24 +248,30 @@ void launch_interp_tiled(hipStream_t st, const double4 *ps_grid, const int *orde
 }
 
 bool launch_anterp_tiled(hipStream_t st, const double4 *ps_grid, const int *gstart, const SplineParams &sp, const TileGeom &tl,
-                         double *scratch, double *grid) {
+                         double *scratch, int *tile_used, double *grid) {
     const size_t n = (size_t)sp.M[0] * sp.M[1] * sp.nz;
     const int gb = (int)((n + 255) / 256);
     static bool attr4 = false, attr6 = false;
     if (sp.p == 4) {
         const size_t bytes = 4 * sizeof(double) * (AT + 3) * (AT + 3) * (AT + 3);
         auto kern = k_anterp_tiles<4>;
-        if (!attr4 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+        if (!attr4 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
         attr4 = true;
-        hipLaunchKernelGGL(kern, dim3(tl.ntiles), dim3(256), bytes, st, ps_grid, gstart, sp, tl, scratch);
-        hipLaunchKernelGGL((k_anterp_combine<4>), dim3(gb), dim3(256), 0, st, scratch, sp, tl, grid);
+        hipLaunchKernelGGL(kern, dim3(tl.ntiles), dim3(256), bytes, st, ps_grid, gstart, sp, tl, scratch, tile_used);
+        hipLaunchKernelGGL((k_anterp_combine<4>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
     } else {
         const size_t bytes = 4 * sizeof(double) * (AT + 5) * (AT + 5) * (AT + 5);
         auto kern = k_anterp_tiles<6>;
-        if (!attr6 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+        if (!attr6 && hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
         attr6 = true;
-        hipLaunchKernelGGL(kern, dim3(tl.ntiles), dim3(256), bytes, st, ps_grid, gstart, sp, tl, scratch);
-        hipLaunchKernelGGL((k_anterp_combine<6>), dim3(gb), dim3(256), 0, st, scratch, sp, tl, grid);
+        hipLaunchKernelGGL(kern, dim3(tl.ntiles), dim3(256), bytes, st, ps_grid, gstart, sp, tl, scratch, tile_used);
+        hipLaunchKernelGGL((k_anterp_combine<6>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
     }
     return true;
 }

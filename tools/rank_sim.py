@@ -1,0 +1,29 @@
+"""Time the work of ONE rank of a W-rank slab decomposition on one GPU (collectives replaced by no-ops)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+import msm_amd
+from msm_amd.slab import SlabRank
+from bench import make_system, SlabProfiler
+
+class FakeWork:
+    def wait(self): pass
+class FakeDist:
+    def get_backend(self): return "nccl"
+    def all_gather_into_tensor(self, out, inp, async_op=False): return FakeWork()
+    def all_reduce(self, t): return None
+
+N = 1000000; p = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+W = int(sys.argv[1])
+r, q = make_system(N, 20261113)
+desc = msm_amd.plan_auto(N, (1.0, 1.0, 1.0), p, 10, 4.0, 0)
+s = SlabRank(torch, FakeDist(), msm_amd, desc, r, q, W // 2, W, 0)
+for _ in range(3): s.step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20): s.step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 20
+prof = SlabProfiler(torch, s).profile(5)
+print("W", W, "p", p, "n_own", s.n_own, "n_tot", s.n_tot, "ms/step", round(dt * 1e3, 3), {k: round(v, 3) for k, v in prof.items()})
