@@ -113,6 +113,12 @@ msm_stats msmperiodic(int N, double *r, double *q, int p, double abar, int mu, d
 double msmPeriodicRunner(double *r, double *q, double *f, int n, int p, int mu, double abar, double Lx, double Ly,
                          double Lz);
 
+/* Open-boundary direct sum on the GPU: *ureal = 1/2 sum_{i!=j} q_i q_j / r_ij, freal[3N] = gradient of the
+ * potential at every particle (acc_i = -sum_j q_j (r_i - r_j) / r_ij^3), host pointers.
+ * replaces direct(), declared at msm/msmLibrary.h:212 and defined nowhere in the reference; the energy is the
+ * computation of msm/nonperiodic.c:12-22 (which forces q = 1). */
+void direct(int N, double *r, double *q, double *ureal, double *freal);
+
 /* parameter helpers, msm/msmLibrary.h:191-192,238-247 / msm/msmLibrary.c:3,31,46,69,110,283 */
 double mylog2(double x);
 double choosebetaNew(double epsilon, double aL, double hL);
@@ -269,6 +275,14 @@ int msm_amd_hostplan_copy_stencil(msm_amd_hostplan *hp, int level, double *host_
 int msm_amd_hostplan_copy_wprime(msm_amd_hostplan *hp, double *host_out, int *len);
 /* scalars: [csr, self_image_sum, gamma(0), chisum, J0, J1, J2, J3] */
 int msm_amd_hostplan_scalars(msm_amd_hostplan *hp, double out[8]);
+
+/* device-resident direct sum for particles [i0, i1) against all N (a rank of a multi-GPU run takes a slice of i
+ * and the slice energies add up): d_acc[3 (i1 - i0)], d_work[msm_amd_direct_work_doubles(N)], stream = hipStream_t;
+ * the slice energy is left in d_work[0] and copied to *u when u != NULL (synchronises).  No counterpart in the
+ * reference beyond direct() above. */
+int msm_amd_direct_work_doubles(int N);
+int msm_amd_direct_device(int N, const double *d_r, const double *d_q, int i0, int i1, int acc_convention, double *d_acc,
+                          double *d_work, void *stream, double *u);
 
 const char *msm_amd_last_error(void);
 int msm_amd_device_count(void);

@@ -245,6 +245,20 @@ class Engine:
         return dict(zip(names, ms))
 
 
+def direct(r, q):
+    """direct() of msm/msmLibrary.h:212 through the C ABI: open-boundary all-pairs energy and potential gradient.
+
+    Returns (u: float, acc: (N,3) array)."""
+    lib = load()
+    r = np.ascontiguousarray(r, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    n = q.shape[0]
+    f = np.zeros((n, 3))
+    u = C.c_double(0.0)
+    lib.direct(n, r.ctypes.data_as(_dp), q.ctypes.data_as(_dp), C.byref(u), f.ctypes.data_as(_dp))
+    return u.value, f
+
+
 def msmperiodic(r, q, p, abar, mu, A, mode=None, quiet=True):
     """msmperiodic() of msm/msmLibrary.h:188 through the C ABI.
 

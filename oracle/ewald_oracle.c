@@ -110,3 +110,26 @@ double or_ewald(int N, const double *r, const double *q, double Ax, double Ay, d
     free(Ck); free(Sk); free(Fk);
     return etot;
 }
+
+/* Open-boundary direct sum, the loop of msm/nonperiodic.c:12-22 (which forces q = 1 first and has no gradient):
+ * returns 1/2 sum_{i != j} q_i q_j / r_ij; acc (may be NULL) receives the gradient of the potential at the first
+ * nsub particles, acc_i = -sum_j q_j (r_i - r_j) / r_ij^3. */
+double or_direct(int N, const double *r, const double *q, int nsub, double *acc, int nthreads) {
+    double u = 0.0;
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for reduction(+ : u) schedule(static)
+    for (int i = 0; i < N; i++) {
+        double phi = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+        for (int j = 0; j < N; j++) {
+            if (i == j) continue;
+            const double dx = r[3 * i] - r[3 * j], dy = r[3 * i + 1] - r[3 * j + 1], dz = r[3 * i + 2] - r[3 * j + 2];
+            const double d2 = dx * dx + dy * dy + dz * dz, d = sqrt(d2);
+            phi += q[j] / d;
+            const double s = q[j] / (d2 * d);
+            gx -= s * dx; gy -= s * dy; gz -= s * dz;
+        }
+        u += 0.5 * q[i] * phi;
+        if (acc && i < nsub) { acc[3 * i] = gx; acc[3 * i + 1] = gy; acc[3 * i + 2] = gz; }
+    }
+    return u;
+}

@@ -19,7 +19,7 @@ msmExpected (grid-free energy components), ewaldClassical totals, and a sweep
 of the parameter helpers chooseM/choosebetaNew/choosekmax through
 _ref/libmsmref.so.
 
-Usage:  python oracle/gen_golden.py [--jobs 6] [--only periodic|simple|expected|ewald|helpers]
+Usage:  python oracle/gen_golden.py [--jobs 6] [--only periodic|simple|expected|ewald|helpers|nonperiodic]
 """
 import argparse
 import ctypes
@@ -182,6 +182,15 @@ def run_ewald(name, alpha, cd, cf):
                                              "total": float(res.stdout.split()[-1])}
 
 
+def run_nonperiodic(name):
+    """msm/nonperiodic.c: open-boundary direct energy with every charge forced to 1; prints `u is %15.8e`."""
+    src = os.path.join(DATA, "benchmark_%s.txt" % name)
+    res = subprocess.run([os.path.join(REF, "nonperiodic"), src], capture_output=True, text=True, check=True)
+    m = re.search(r"u is\s+([-+0-9.eE]+)", res.stdout)
+    return "nonperiodic_%s.json" % name, {"program": "nonperiodic", "args": [name], "u": float(m.group(1)),
+                                          "printed": m.group(1), "system": read_system(src)}
+
+
 def run_helpers():
     lib = ctypes.CDLL(os.path.join(REF, "libmsmref.so"))
     lib.chooseM.restype = ctypes.c_int
@@ -259,6 +268,8 @@ def main():
                  ("run_ewald", ("changaN512", 24, 10, 60))]
     if a.only in ("", "helpers"):
         jobs.append(("run_helpers", ()))
+    if a.only in ("", "nonperiodic"):
+        jobs += [("run_nonperiodic", (nm,)) for nm in ("changaN8", "changaN64", "changaN512", "NaClN64", "CsClN128")]
     with ProcessPoolExecutor(max_workers=a.jobs) as ex:
         futs = {ex.submit(_call, j): j for j in jobs}
         for fu in as_completed(futs):

@@ -118,6 +118,7 @@ void or_spec_interpolate(const or_spec_plan *pl, const double *r, const double *
 double or_ewald(int N, const double *r, const double *q, double Ax, double Ay, double Az, double alpha, double rcut,
                 int kcut, int nsub, double *acc, int nthreads);
 /* literal restatement of ewaldClassical() (ewaldClassical.c:5-109): no image loop */
+double or_direct(int N, const double *r, const double *q, int nsub, double *acc, int nthreads);
 double or_ewald_classical(const double *r, const double *q, int N, double Lx, double Ly, double Lz, double alpha,
                           double cutoffDirect, double cutoffFourier);
 

@@ -132,6 +132,8 @@ def lib():
     L.or_spec_interpolate.argtypes = [C.c_void_p, _dp, _dp, _dp]
     L.or_ewald.restype = C.c_double
     L.or_ewald.argtypes = [C.c_int, _dp, _dp] + [C.c_double] * 5 + [C.c_int, C.c_int, _dp, C.c_int]
+    L.or_direct.restype = C.c_double
+    L.or_direct.argtypes = [C.c_int, _dp, _dp, C.c_int, _dp, C.c_int]
     L.or_ewald_classical.restype = C.c_double
     L.or_ewald_classical.argtypes = [_dp, _dp, C.c_int] + [C.c_double] * 6
     _lib = L
@@ -326,6 +328,16 @@ def ewald(r, q, A, alpha, rcut, kcut, nsub=None, nthreads=0):
     acc = np.zeros(3 * nsub)
     u = lib().or_ewald(n, rp, qp, A[0], A[1], A[2], alpha, rcut, kcut, nsub, acc.ctypes.data_as(_dp), nthreads)
     return u, acc.reshape(nsub, 3)
+
+
+def direct(r, q, nthreads=0):
+    """Open-boundary direct sum (msm/nonperiodic.c:12-22 plus the gradient): (u, acc)."""
+    r, rp = _arr(r)
+    q, qp = _arr(q)
+    n = len(q)
+    acc = np.zeros(3 * n)
+    u = lib().or_direct(n, rp, qp, n, acc.ctypes.data_as(_dp), nthreads)
+    return u, acc.reshape(n, 3)
 
 
 def neutral_system(N, A=(1.0, 1.0, 1.0), seed=20261111):

@@ -404,3 +404,49 @@ def test_accuracy_vs_ewald_100k(msm, torch):
     ferr = rel_rms(acc[:nsub], aE)
     assert ferr < 2e-3, ferr
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["changaN8", "changaN64", "changaN512", "NaClN64", "CsClN128"])
+def test_direct_matches_reference_nonperiodic(msm, name):
+    """direct() (msm/msmLibrary.h:212) on the GPU == the reference's msm/nonperiodic output (charges forced to 1
+    there, energy printed with %15.8e) and == the CPU oracle to rounding on the system's own charges."""
+    fx = O.golden("nonperiodic_%s.json" % name)
+    s = fx["system"]
+    r, q = np.array(s["r"]).reshape(-1, 3), np.array(s["q"])
+    u1, _ = msm.direct(r, np.ones(s["N"]))
+    assert "%15.8e" % u1 == "%15s" % fx["printed"]
+    u, acc = msm.direct(r, q)
+    uo, acco = O.direct(r, q)
+    assert abs(u - uo) <= 1e-13 * np.abs(q).sum() ** 2 / np.abs(r).max()
+    assert rel_rms(acc, acco) < TOL
+
+
+def test_direct_large(msm, torch):
+    """20k random charges: every lane of the all-pairs kernel is live; slices of i (the multi-GPU split) add up."""
+    import ctypes as C
+    N = 20000
+    r, q = O.neutral_system(N, (3.0, 2.0, 1.0), seed=11)
+    r[7] = r[3]                                    # an exact duplicate contributes nothing (and no NaN)
+    u, acc = msm.direct(r, q)
+    assert np.isfinite(u) and np.isfinite(acc).all()
+    lib = msm.load()
+    rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
+    work = torch.zeros(lib.msm_amd_direct_work_doubles(N), dtype=torch.float64, device="cuda:0")
+    parts, usum = [], 0.0
+    for i0, i1 in ((0, 7000), (7000, 7001), (7001, N)):
+        a = torch.zeros((i1 - i0, 3), dtype=torch.float64, device="cuda:0")
+        us = C.c_double()
+        rc = lib.msm_amd_direct_device(N, rd.data_ptr(), qd.data_ptr(), i0, i1, msm.capi.ACC_GRADIENT, a.data_ptr(),
+                                       work.data_ptr(), None, C.byref(us))
+        assert rc == 0
+        parts.append(a.cpu().numpy())
+        usum += us.value
+    assert np.array_equal(np.concatenate(parts), acc)
+    assert abs(usum - u) <= 1e-12 * abs(u)
+    # against the CPU oracle on a perturbed copy without the coincidence
+    r2 = r.copy()
+    r2[7] += 0.01
+    u2, acc2 = msm.direct(r2, q)
+    uo2, acco2 = O.direct(r2, q)
+    assert abs(u2 - uo2) <= 1e-12 * np.abs(acco2).max()
+    assert rel_rms(acc2, acco2) < TOL

@@ -234,3 +234,21 @@ def test_ewald_classical_matches_reference():
     _, r, q, A = system("NaClN64")
     u2, _ = O.ewald(r, q, A, 1.5, 3.99, 13, nthreads=8)  # a different splitting must give the same total
     assert abs(u2 - O.golden("ewaldClassical_NaClN64.json")["total"]) < 1e-6 * abs(u2)
+
+
+@pytest.mark.parametrize("name", ["changaN8", "changaN64", "changaN512", "NaClN64", "CsClN128"])
+def test_direct_oracle_matches_reference_nonperiodic(name):
+    """The oracle's open-boundary direct sum against the real msm/nonperiodic (prints %15.8e; charges forced to 1)."""
+    fx = O.golden("nonperiodic_%s.json" % name)
+    s = fx["system"]
+    r = np.array(s["r"]).reshape(-1, 3)
+    u, acc = O.direct(r, np.ones(s["N"]))
+    assert abs(u - fx["u"]) <= 0.6e-8 * abs(fx["u"])       # the printed precision
+    assert "%15.8e" % u == "%15s" % fx["printed"]
+    # the gradient is the derivative of the energy: central difference on one coordinate
+    eps = 1e-6 * np.abs(r).max()
+    rp, rm = r.copy(), r.copy()
+    rp[1, 0] += eps
+    rm[1, 0] -= eps
+    du = (O.direct(rp, np.ones(s["N"]))[0] - O.direct(rm, np.ones(s["N"]))[0]) / (2 * eps)
+    assert abs(du - acc[1, 0]) <= 1e-6 * max(abs(du), np.abs(acc).max() * 1e-3)
