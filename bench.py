@@ -9,7 +9,7 @@ prolongations -> interpolation -> energy reductions (and, for N > 1 ranks, the l
 the energy all-reduce).  Position-independent setup (beta, kmax, omega', stencils, allocation, communicator)
 is outside the timed region.  Positions are perturbed between steps so nothing can be cached.
 
-Workload: BASELINE.json configs[2] (the configuration the metric is quoted on): 1,000,000 charge-neutral
+Workload (the configuration the headline metric is quoted on): 1,000,000 charge-neutral
 particles in a periodic unit cube, quintic B-spline (p = 6) unless --order 4, abar = 4, mu = 10, four grid
 levels 96 -> 48 -> 24 -> 12 plus the Fourier top level.  N > 1 keeps the total work fixed (strong scaling):
 the same million particles are split into z slabs.

@@ -23,13 +23,6 @@ namespace msm {
 // ---------------------------------------------------------------------------
 // sort into columns / fine z bins, cut into clusters, bounding boxes
 // ---------------------------------------------------------------------------
-// Column number of column (cx, cy): tiles of 8 x 8 columns, tile after tile.  Clusters are numbered in column
-// order and waves take clusters in that order, so the waves in flight at any time work on a compact patch of
-// columns and find their neighbours' particles in L2 instead of fetching them once per row of columns.
-__device__ __forceinline__ int cl_col(const ClusterGeom &g, int cx, int cy) {
-    return (((cy >> 3) * g.ntx + (cx >> 3)) << 6) + ((cy & 7) << 3) + (cx & 7);
-}
-
 __global__ void k_cl_count(const double *__restrict__ r, int N, ClusterGeom g, int *__restrict__ bin_of, int *__restrict__ count,
                            int *__restrict__ arrival) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -40,7 +33,9 @@ __global__ void k_cl_count(const double *__restrict__ r, int N, ClusterGeom g, i
         double t = r[3 * (size_t)i + d] * g.invA[d];
         s[d] = t - floor(t);
     }
-    const int cx = min((int)(s[0] * g.ncx), g.ncx - 1), cy = min((int)(s[1] * g.ncy), g.ncy - 1);
+    // grid-aligned columns are made of whole level-0 grid cells, so that a tile of cells is a set of columns
+    const int cx = g.kx ? min((int)(s[0] * (g.ncx * g.kx)), g.ncx * g.kx - 1) / g.kx : min((int)(s[0] * g.ncx), g.ncx - 1);
+    const int cy = g.ky ? min((int)(s[1] * (g.ncy * g.ky)), g.ncy * g.ky - 1) / g.ky : min((int)(s[1] * g.ncy), g.ncy - 1);
     const int zf = min((int)(s[2] * g.nzf), g.nzf - 1);
     const int b = cl_col(g, cx, cy) * g.nzf + zf;
     bin_of[i] = b;

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "msm_kernels.hpp"
+
 namespace msm {
 
 // Blocks b and b+8 share an XCD (and its L2).  Give each XCD a contiguous run of
@@ -18,6 +20,13 @@ __device__ __forceinline__ int wrap1(int i, int M) { // i in [-M, 2M)
 __device__ __forceinline__ int modp(int i, int M) {
     int r = i % M;
     return r < 0 ? r + M : r;
+}
+
+// Column number of column (cx, cy): tiles of 8 x 8 columns, tile after tile.  Clusters are numbered in column
+// order and waves take clusters in that order, so the waves in flight at any time work on a compact patch of
+// columns and find their neighbours' particles in L2 instead of fetching them once per row of columns.
+__device__ __forceinline__ int cl_col(const ClusterGeom &g, int cx, int cy) {
+    return (((cy >> 3) * g.ntx + (cx >> 3)) << 6) + ((cy & 7) << 3) + (cx & 7);
 }
 
 __device__ __forceinline__ double wave_sum(double v) {

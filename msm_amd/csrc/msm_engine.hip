@@ -64,7 +64,7 @@ struct msm_amd_handle {
     // cluster-pair path of the short-range sum
     ClusterGeom clg;
     ClusterBuffers clb = {};
-    bool cells_binned = false, clusters_sorted = false;
+    bool cells_binned = false, clusters_sorted = false, grid_binned = false;
     // LDS-tiled anterpolation
     TileGeom tiles = {};
     double *tile_scratch = nullptr;
@@ -202,13 +202,45 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         if (d.nzplanes < d.M[2]) occ = std::min(1.0, (d.nzplanes + 2.0 * (d.a / h->hp.hl[0][2] + d.p / 2)) / d.M[2]);
         const double vol = d.A[0] * d.A[1] * d.A[2] * occ;
         const double c = std::cbrt(CL_G * vol / std::max(N, 1));
-        cg.ncx = std::max(1, (int)std::floor(d.A[0] / c + 0.5));
-        cg.ncy = std::max(1, (int)std::floor(d.A[1] / c + 0.5));
+        // One sort for everything when the level-0 grid allows it: columns of kx x ky whole grid cells (k a
+        // divisor of the spline tile edge, nearest the ideal pitch) and kz fine bins per cell along z, so that a
+        // tile of grid cells is a set of columns and a run of fine bins.
+        cg.kx = cg.ky = cg.kz = 0;
+        const bool tiled_grid = !literal && d.M[0] >= 24 && d.M[1] >= 24 && d.M[2] >= 24;
+        if (tiled_grid && d.acc_convention != MSM_AMD_ACC_LITERAL) {
+            auto pick = [&](double h, int M) {
+                int best = 0;
+                double bd = 1e300;
+                for (int k = 1; k <= SPLINE_TILE; k *= 2) {
+                    const double dist = std::fabs(std::log(k * h / c));
+                    if (M % k == 0 && dist < bd) { bd = dist; best = k; }
+                }
+                return best;
+            };
+            cg.kx = pick(h->hp.hl[0][0], d.M[0]);
+            cg.ky = pick(h->hp.hl[0][1], d.M[1]);
+            const double hz = h->hp.hl[0][2];
+            int kz = (int)std::floor(8.0 * hz / c + 0.5);
+            kz = std::max(1, std::min(kz, 16));
+            while (kz > 1 && (long)(d.M[0] / cg.kx + 7) * (d.M[1] / cg.ky + 7) * d.M[2] * kz > 6L * N + 65536) kz--;
+            cg.kz = kz;
+        }
+        if (cg.kx) {
+            cg.ncx = d.M[0] / cg.kx;
+            cg.ncy = d.M[1] / cg.ky;
+        } else {
+            cg.ncx = std::max(1, (int)std::floor(d.A[0] / c + 0.5));
+            cg.ncy = std::max(1, (int)std::floor(d.A[1] / c + 0.5));
+        }
         cg.ntx = (cg.ncx + 7) / 8;
         cg.ncols = cg.ntx * ((cg.ncy + 7) / 8) * 64;
-        long nzf = std::max(1L, (long)std::floor(8.0 * d.A[2] / c + 0.5));
-        nzf = std::min(nzf, std::max(1L, (4L * N + 1024) / cg.ncols));
-        cg.nzf = (int)nzf;
+        if (cg.kx) {
+            cg.nzf = d.M[2] * cg.kz;
+        } else {
+            long nzf = std::max(1L, (long)std::floor(8.0 * d.A[2] / c + 0.5));
+            nzf = std::min(nzf, std::max(1L, (4L * N + 1024) / cg.ncols));
+            cg.nzf = (int)nzf;
+        }
         cg.nbins = cg.ncols * cg.nzf;
         cg.max_clusters = (N + CL_G - 1) / CL_G + cg.ncols;
         cg.list_stride = 256;
@@ -357,6 +389,31 @@ static inline void mark(msm_amd_handle *h, int slot) {
     if (h->profiling) hipEventRecord(h->ev[slot], h->stream);
 }
 
+// the tiled spline kernels read the cluster order when the columns are grid aligned and that sort was made
+static bool tiles_from_clusters(const msm_amd_handle *h) {
+    return h->anterp_tiled && h->opt_anterp_tiled && h->clg.kx > 0 && !h->small_box && h->clusters_sorted;
+}
+static void ensure_grid_binned(msm_amd_handle *h) {
+    if (h->grid_binned) return;
+    launch_bin(h->stream, h->cur_r, h->cur_q, h->N, h->gridg, h->bin_of, h->gcount, h->gstart, h->arrival, h->slot_idx,
+               h->scan_tmp, h->order_grid, h->ps_grid);
+    h->grid_binned = true;
+}
+static TileSrc tile_source(msm_amd_handle *h) {
+    TileSrc S;
+    memset(&S, 0, sizeof(S));
+    if (tiles_from_clusters(h)) {
+        S.ps = h->clb.ps; S.order = h->clb.order; S.start = h->clb.start; S.clstart = h->clb.clstart;
+        S.cg = h->clg; S.cluster_order = 1;
+        for (int k = 0; k < 3; k++) S.scale[k] = h->hp.d.M[k] / h->hp.d.A[k];
+    } else {
+        ensure_grid_binned(h);
+        S.ps = h->ps_grid; S.order = h->order_grid; S.start = h->gstart; S.cluster_order = 0;
+        for (int k = 0; k < 3; k++) S.scale[k] = 1.0;
+    }
+    return S;
+}
+
 extern "C" int msm_amd_stage_bin(msm_amd_handle *h, const double *d_r, const double *d_q) {
     if (!h || !d_r || !d_q) { set_error("stage_bin: null argument"); return MSM_AMD_EINVAL; }
     h->cur_r = d_r;
@@ -374,8 +431,9 @@ extern "C" int msm_amd_stage_bin(msm_amd_handle *h, const double *d_r, const dou
             h->cells_binned = true;
         }
     }
-    launch_bin(h->stream, d_r, d_q, h->N, h->gridg, h->bin_of, h->gcount, h->gstart, h->arrival, h->slot_idx, h->scan_tmp,
-               h->order_grid, h->ps_grid);
+    // the grid-cell order is needed unless the tile kernels can walk the cluster order
+    h->grid_binned = false;
+    if (!tiles_from_clusters(h)) ensure_grid_binned(h);
     HIPCHK(hipGetLastError());
     return MSM_AMD_OK;
 }
@@ -412,8 +470,10 @@ extern "C" int msm_amd_stage_pairs(msm_amd_handle *h, double *d_acc) {
 extern "C" int msm_amd_stage_anterpolate(msm_amd_handle *h) {
     if (!h || !h->cur_r) { set_error("stage_anterpolate: bin first"); return MSM_AMD_EINVAL; }
     if (!(h->anterp_tiled && h->opt_anterp_tiled &&
-          launch_anterp_tiled(h->stream, h->ps_grid, h->gstart, h->sp, h->tiles, h->tile_scratch, h->tile_used, h->gq[0])))
+          launch_anterp_tiled(h->stream, tile_source(h), h->sp, h->tiles, h->tile_scratch, h->tile_used, h->gq[0]))) {
+        ensure_grid_binned(h);
         launch_anterp(h->stream, h->ps_grid, h->gstart, h->sp, h->gq[0]);
+    }
     HIPCHK(hipGetLastError());
     return MSM_AMD_OK;
 }
@@ -528,10 +588,12 @@ extern "C" int msm_amd_stage_interpolate(msm_amd_handle *h, double *d_acc) {
     if (!h || !d_acc || !h->cur_r) { set_error("stage_interpolate: bin first"); return MSM_AMD_EINVAL; }
     // literal: grid index = node + p/2 - 1 (msmPeriodic.c:1136-1151)
     const int shift = h->hp.literal ? h->hp.d.p / 2 - 1 : 0;
-    if (h->anterp_tiled && h->opt_anterp_tiled)
-        launch_interp_tiled(h->stream, h->ps_grid, h->order_grid, h->gstart, h->sp, h->tiles, h->ge[0], d_acc);
-    else
+    if (h->anterp_tiled && h->opt_anterp_tiled) {
+        launch_interp_tiled(h->stream, tile_source(h), h->sp, h->tiles, h->ge[0], d_acc);
+    } else {
+        ensure_grid_binned(h);
         launch_interp(h->stream, h->ps_grid, h->order_grid, h->N, h->sp, h->ge[0], shift, d_acc);
+    }
     HIPCHK(hipGetLastError());
     return MSM_AMD_OK;
 }

@@ -72,6 +72,7 @@ void launch_bin_scatter(hipStream_t st, const int *bin_of, const int *arrival, i
 #define CL_G 8
 struct ClusterGeom {
     int ncx, ncy, nzf;   // columns along x and y, fine z bins per column
+    int kx, ky, kz;      // grid-aligned columns (0 if not): kx x ky level-0 grid cells per column, kz fine bins per cell
     int ntx;             // column tiles along x: columns are numbered tile by tile (8 x 8 columns per tile), see cl_col()
     int ncols, nbins;    // column numbers in use (whole tiles, some columns empty), ncols*nzf
     int max_clusters;    // capacity of the per-cluster arrays: ceil(N/CL_G) + ncols
@@ -109,10 +110,21 @@ void launch_pair_allimages(hipStream_t st, const double *d_r, const double *d_q,
 void launch_anterp(hipStream_t st, const double4 *ps_grid, const int *gstart, const SplineParams &sp, double *grid);
 // LDS-tiled form; scratch holds ntiles * (SPLINE_TILE + p - 1)^3 doubles.  Needs M >= 24 on every axis and the
 // plain index convention (no node_shift / drop_last).
-bool launch_anterp_tiled(hipStream_t st, const double4 *ps_grid, const int *gstart, const SplineParams &sp, const TileGeom &tl,
-                         double *scratch, int *tile_used, double *grid);
-void launch_interp_tiled(hipStream_t st, const double4 *ps_grid, const int *order, const int *gstart, const SplineParams &sp,
-                         const TileGeom &tl, const double *egrid, double *acc);
+// Where a tile kernel finds its particles: slots of a sorted particle array in grid-cell order (runs = rows of
+// cells, coordinates already in grid units) or in cluster order (runs = columns, absolute coordinates).
+struct TileSrc {
+    const double4 *ps;
+    const int *order;
+    const int *start;    // per grid cell (grid-cell order) or per fine bin (cluster order), exclusive prefix sums
+    const int *clstart;  // cluster order only
+    ClusterGeom cg;      // cluster order only
+    int cluster_order;
+    double scale[3];     // slot coordinate -> grid units
+};
+bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, double *scratch,
+                         int *tile_used, double *grid);
+void launch_interp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, const double *egrid,
+                         double *acc);
 void launch_interp(hipStream_t st, const double4 *ps_grid, const int *order, int N, const SplineParams &sp,
                    const double *egrid, int index_shift, double *acc);
 // one axis of the separable restriction: out has the axis halved.  J[0..p/2]

@@ -30,9 +30,32 @@ __device__ __forceinline__ double piece_eval(const double *c, double f) {
     return w;
 }
 
+// The particles of a tile are a few runs of consecutive slots of a sorted particle array: in grid-cell order
+// one run per (y, z) row of cells; in cluster order (columns of kx x ky cells, sorted by z) one run per column.
+__device__ __forceinline__ int tile_runs(const TileSrc &S, int nxc, int nyc, int nzc) {
+    return S.cluster_order ? (nxc / S.cg.kx) * (nyc / S.cg.ky) : nyc * nzc;
+}
+__device__ __forceinline__ void tile_run(const TileSrc &S, const SplineParams &sp, int x0, int y0, int z0, int nxc, int nyc,
+                                         int nzc, int t, int &first, int &cnt) {
+    if (S.cluster_order) {
+        const int ncx = nxc / S.cg.kx;
+        const int col = cl_col(S.cg, x0 / S.cg.kx + t % ncx, y0 / S.cg.ky + t / ncx);
+        const int b = col * S.cg.nzf;
+        const int colp0 = S.start[b], p0 = S.start[b + z0 * S.cg.kz], p1 = S.start[b + (z0 + nzc) * S.cg.kz];
+        first = CL_G * S.clstart[col] + (p0 - colp0);
+        cnt = p1 - p0;
+    } else {
+        const int b0 = ((z0 + t / nyc) * sp.M[1] + (y0 + t % nyc)) * sp.M[0] + x0;
+        first = S.start[b0];
+        cnt = S.start[b0 + nxc] - first;
+    }
+}
+
+// cell of a coordinate (grid units), kept inside the tile whatever the last bit of the product did
+__device__ __forceinline__ int tile_cell(double u, int c0, int n) { return min(max((int)u, c0), c0 + n - 1); }
+
 template <int P>
-__global__ __launch_bounds__(256) void k_anterp_tiles(const double4 *__restrict__ ps, const int *__restrict__ gstart,
-                                                      SplineParams sp, TileGeom tl, double *__restrict__ scratch,
+__global__ __launch_bounds__(256) void k_anterp_tiles(TileSrc S, SplineParams sp, TileGeom tl, double *__restrict__ scratch,
                                                       int *__restrict__ tile_used) {
     constexpr int R = AT + P - 1, R3 = R * R * R;
     extern __shared__ double lds[]; // 4 copies of the node block
@@ -44,12 +67,14 @@ __global__ __launch_bounds__(256) void k_anterp_tiles(const double4 *__restrict_
     const int Mx = sp.M[0], My = sp.M[1], Mz = sp.M[2];
     const int x0 = tx * AT, y0 = ty * AT, z0 = tz * AT;
     const int nxc = min(AT, Mx - x0), nyc = min(AT, My - y0), nzc = min(AT, Mz - z0);
+    const int nruns = tile_runs(S, nxc, nyc, nzc);
     // an empty tile (most tiles of a slab rank) is only flagged; the combine kernel then skips its block
     if (threadIdx.x == 0) any_particle = 0;
     __syncthreads();
-    if ((int)threadIdx.x < nyc * nzc) {
-        const int b0 = ((z0 + (int)threadIdx.x / nyc) * My + (y0 + (int)threadIdx.x % nyc)) * Mx + x0;
-        if (gstart[b0 + nxc] > gstart[b0]) any_particle = 1;
+    if ((int)threadIdx.x < nruns) {
+        int first, cnt;
+        tile_run(S, sp, x0, y0, z0, nxc, nyc, nzc, threadIdx.x, first, cnt);
+        if (cnt > 0) any_particle = 1;
     }
     __syncthreads();
     if (threadIdx.x == 0) tile_used[tile] = any_particle;
@@ -67,31 +92,41 @@ __global__ __launch_bounds__(256) void k_anterp_tiles(const double4 *__restrict_
         cz[n] = sp.piece[c][n];
     }
     const int lane_off = (c * R + b) * R + a;
-    for (int row = wave; row < nyc * nzc; row += 4) {
-        const int ry = row % nyc, rz = row / nyc;
-        const int b0 = ((z0 + rz) * My + (y0 + ry)) * Mx + x0;
-        const int s0 = gstart[b0], s1 = gstart[b0 + nxc];
-        for (int sb = s0; sb < s1; sb += 64) {
-            const int cnt = min(64, s1 - sb);
-            const double4 ptl = lane < cnt ? ps[sb + lane] : make_double4(0, 0, 0, 0);
+    for (int run = wave; run < nruns; run += 4) {
+        int s0, n;
+        tile_run(S, sp, x0, y0, z0, nxc, nyc, nzc, run, s0, n);
+        for (int sb = 0; sb < n; sb += 64) {
+            const int cnt = min(64, n - sb);
+            // every lane prepares one particle of the batch: cell, offset inside the cell, and (p = 6) the six
+            // z weights times the charge; the batch is then spread one particle at a time
+            const double4 ptl = lane < cnt ? S.ps[s0 + sb + lane] : make_double4(0, 0, 0, 0);
+            const double ux = ptl.x * S.scale[0], uy = ptl.y * S.scale[1], uz = ptl.z * S.scale[2];
+            const int celx = tile_cell(ux, x0, nxc), cely = tile_cell(uy, y0, nyc), celz = tile_cell(uz, z0, nzc);
+            const double lfx = ux - (double)celx, lfy = uy - (double)cely, lfz = uz - (double)celz;
+            const int lbase = ((celz - z0) * R + (cely - y0)) * R + (celx - x0);
+            double lwz[P];
+            if (P == 6) {
+#pragma unroll
+                for (int cc = 0; cc < P; cc++) lwz[cc] = ptl.w * piece_eval<P>(sp.piece[cc], lfz);
+            }
             for (int k = 0; k < cnt; k++) {
-                const double px = readlane_d(ptl.x, k), py = readlane_d(ptl.y, k), pz = readlane_d(ptl.z, k), pq = readlane_d(ptl.w, k);
-                const int cellx = min((int)px, Mx - 1);
-                const double fx = px - (double)cellx, fy = py - (double)(y0 + ry), fz = pz - (double)(z0 + rz);
-                const int base = (rz * R + ry) * R + (cellx - x0) + lane_off;
-                const double wxy = pq * piece_eval<P>(cx, fx) * piece_eval<P>(cy, fy);
+                const double fx = readlane_d(lfx, k), fy = readlane_d(lfy, k);
+                const int base = __builtin_amdgcn_readlane(lbase, k) + lane_off;
+                const double wxy = piece_eval<P>(cx, fx) * piece_eval<P>(cy, fy);
                 if (P == 4) {
-                    const double w = wxy * piece_eval<P>(cz, fz);
-                    mine[base] += w;
-                } else if (active) {
+                    const double fz = readlane_d(lfz, k), pq = readlane_d(ptl.w, k);
+                    mine[base] += pq * wxy * piece_eval<P>(cz, fz);
+                } else {
                     double wz[P];
 #pragma unroll
-                    for (int cc = 0; cc < P; cc++) wz[cc] = piece_eval<P>(sp.piece[cc], fz);
-                    double v[P];
+                    for (int cc = 0; cc < P; cc++) wz[cc] = readlane_d(lwz[cc], k);
+                    if (active) {
+                        double v[P];
 #pragma unroll
-                    for (int cc = 0; cc < P; cc++) v[cc] = mine[base + cc * R * R];
+                        for (int cc = 0; cc < P; cc++) v[cc] = mine[base + cc * R * R];
 #pragma unroll
-                    for (int cc = 0; cc < P; cc++) mine[base + cc * R * R] = fma(wxy, wz[cc], v[cc]);
+                        for (int cc = 0; cc < P; cc++) mine[base + cc * R * R] = fma(wxy, wz[cc], v[cc]);
+                    }
                 }
             }
         }
@@ -146,9 +181,8 @@ __global__ __launch_bounds__(256) void k_anterp_combine(const double *__restrict
 // (periodic wrap applied while staging), then every thread takes one particle of the tile and sums its p^3
 // nodes out of LDS.  acc_i += f sum_m e_m grad Phi_m(r_i), f by the acceleration convention.
 template <int P>
-__global__ __launch_bounds__(256) void k_interp_tiles(const double4 *__restrict__ ps, const int *__restrict__ order,
-                                                      const int *__restrict__ gstart, SplineParams sp, TileGeom tl,
-                                                      const double *__restrict__ e, double *__restrict__ acc) {
+__global__ __launch_bounds__(256) void k_interp_tiles(TileSrc S, SplineParams sp, TileGeom tl, const double *__restrict__ e,
+                                                      double *__restrict__ acc) {
     constexpr int R = AT + P - 1, R3 = R * R * R;
     __shared__ double blk[R3];
     __shared__ int rowstart[AT * AT + 1], rowbase[AT * AT];
@@ -157,15 +191,14 @@ __global__ __launch_bounds__(256) void k_interp_tiles(const double4 *__restrict_
     const int Mx = sp.M[0], My = sp.M[1], Mz = sp.M[2];
     const int x0 = tx * AT, y0 = ty * AT, z0 = tz * AT;
     const int nxc = min(AT, Mx - x0), nyc = min(AT, My - y0), nzc = min(AT, Mz - z0);
-    const int nrows = nyc * nzc;
-    if (threadIdx.x < 64) { // rows of the tile: first particle and running count (one wave, shuffle scan)
+    const int nrows = tile_runs(S, nxc, nyc, nzc);
+    if (threadIdx.x < 64) { // runs of the tile: first slot and running count (one wave, shuffle scan)
         const int t = threadIdx.x;
         int cnt = 0;
         if (t < nrows) {
-            const int b0 = ((z0 + t / nyc) * My + (y0 + t % nyc)) * Mx + x0;
-            const int s0 = gstart[b0];
+            int s0;
+            tile_run(S, sp, x0, y0, z0, nxc, nyc, nzc, t, s0, cnt);
             rowbase[t] = s0;
-            cnt = gstart[b0 + nxc] - s0;
         }
         int incl = cnt;
 #pragma unroll
@@ -192,12 +225,12 @@ __global__ __launch_bounds__(256) void k_interp_tiles(const double4 *__restrict_
             if (rowstart[mid] <= idx) lo = mid; else hi = mid;
         }
         const int s = rowbase[lo] + (idx - rowstart[lo]);
-        const int orig = order[s];
+        const int orig = S.order[s];
         if (orig >= sp.n_owned) continue;
-        const double4 pt = ps[s];
-        const int ry = lo % nyc, rz = lo / nyc;
-        const int cellx = min((int)pt.x, Mx - 1);
-        const double f[3] = {pt.x - (double)cellx, pt.y - (double)(y0 + ry), pt.z - (double)(z0 + rz)};
+        const double4 pt = S.ps[s];
+        const double ux = pt.x * S.scale[0], uy = pt.y * S.scale[1], uz = pt.z * S.scale[2];
+        const int cellx = tile_cell(ux, x0, nxc), ry = tile_cell(uy, y0, nyc) - y0, rz = tile_cell(uz, z0, nzc) - z0;
+        const double f[3] = {ux - (double)cellx, uy - (double)(y0 + ry), uz - (double)(z0 + rz)};
         double w[2][P], dw[2][P]; // x and y weights; the z weights are made plane by plane
 #pragma unroll
         for (int d = 0; d < 2; d++)
@@ -241,14 +274,14 @@ __global__ __launch_bounds__(256) void k_interp_tiles(const double4 *__restrict_
     }
 }
 
-void launch_interp_tiled(hipStream_t st, const double4 *ps_grid, const int *order, const int *gstart, const SplineParams &sp,
-                         const TileGeom &tl, const double *egrid, double *acc) {
-    if (sp.p == 4) hipLaunchKernelGGL((k_interp_tiles<4>), dim3(tl.ntiles), dim3(256), 0, st, ps_grid, order, gstart, sp, tl, egrid, acc);
-    else hipLaunchKernelGGL((k_interp_tiles<6>), dim3(tl.ntiles), dim3(256), 0, st, ps_grid, order, gstart, sp, tl, egrid, acc);
+void launch_interp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, const double *egrid,
+                         double *acc) {
+    if (sp.p == 4) hipLaunchKernelGGL((k_interp_tiles<4>), dim3(tl.ntiles), dim3(256), 0, st, S, sp, tl, egrid, acc);
+    else hipLaunchKernelGGL((k_interp_tiles<6>), dim3(tl.ntiles), dim3(256), 0, st, S, sp, tl, egrid, acc);
 }
 
-bool launch_anterp_tiled(hipStream_t st, const double4 *ps_grid, const int *gstart, const SplineParams &sp, const TileGeom &tl,
-                         double *scratch, int *tile_used, double *grid) {
+bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, double *scratch,
+                         int *tile_used, double *grid) {
     const size_t n = (size_t)sp.M[0] * sp.M[1] * sp.nz;
     const int gb = (int)((n + 255) / 256);
     static bool attr4 = false, attr6 = false;
@@ -260,7 +293,7 @@ bool launch_anterp_tiled(hipStream_t st, const double4 *ps_grid, const int *gsta
             return false;
         }
         attr4 = true;
-        hipLaunchKernelGGL(kern, dim3(tl.ntiles), dim3(256), bytes, st, ps_grid, gstart, sp, tl, scratch, tile_used);
+        hipLaunchKernelGGL(kern, dim3(tl.ntiles), dim3(256), bytes, st, S, sp, tl, scratch, tile_used);
         hipLaunchKernelGGL((k_anterp_combine<4>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
     } else {
         const size_t bytes = 4 * sizeof(double) * (AT + 5) * (AT + 5) * (AT + 5);
@@ -270,7 +303,7 @@ bool launch_anterp_tiled(hipStream_t st, const double4 *ps_grid, const int *gsta
             return false;
         }
         attr6 = true;
-        hipLaunchKernelGGL(kern, dim3(tl.ntiles), dim3(256), bytes, st, ps_grid, gstart, sp, tl, scratch, tile_used);
+        hipLaunchKernelGGL(kern, dim3(tl.ntiles), dim3(256), bytes, st, S, sp, tl, scratch, tile_used);
         hipLaunchKernelGGL((k_anterp_combine<6>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
     }
     return true;
