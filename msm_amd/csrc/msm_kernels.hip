@@ -1052,7 +1052,7 @@ bool launch_conv_tiled(hipStream_t st, const double *q, const double *Kt, const 
 // owns R consecutive outputs along z; for every (sx, sy) it reads a window of R + SZ - 1 inputs from the LDS
 // tile and feeds R * SZ FMAs whose stencil taps are wave-uniform (scalar loads).  With one wave per SIMD (the
 // tile takes almost all of the LDS) nothing else hides latency, so the window and the taps of the next
-// (sx, sy) are fetched before the FMAs of the current one are issued.
+// (sx, sy) are requested before the FMAs of the current one are issued.
 template <int SZ, int R, int TX, int TY, int TZ>
 __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
     extern __shared__ double lds[];
@@ -1064,77 +1064,89 @@ __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
     double *__restrict__ e = B.e[lev];
     const int ntx = B.ntx[lev], nty = B.nty[lev];
     const int Mx = c.M[0], My = c.M[1], Mz = c.M[2];
-    const int sxn = c.ks[0], syn = c.ks[1];
-    const int LX = TX + sxn - 1, LY = TY + syn - 1, LZ = TZ + SZ - 1;
+    // LDS tile [z][x][y], y fastest, row length LY = 2 mod 4 doubles: the 16 x 2 (x, y) lanes of a half wave then
+    // fall on 64 different banks, so a window read costs its two LDS cycles and no more
+    constexpr int LX = TX + SZ - 1, LY = ((TY + SZ - 1 + 1) / 4) * 4 + 2, LZ = TZ + SZ - 1;
+    static_assert(LY >= TY + SZ - 1, "row padding");
     const int bid = blockIdx.x - B.blk0[lev];
     const int bx = bid % ntx, by = (bid / ntx) % nty, bz = bid / (ntx * nty);
     const int X0 = bx * TX, Y0 = by * TY, Z0 = c.z0 + bz * TZ;
-    const int ox = X0 - (c.kf[0] + sxn - 1), oy = Y0 - (c.kf[1] + syn - 1), oz = Z0 - (c.kf[2] + SZ - 1);
+    const int ox = X0 - (c.kf[0] + SZ - 1), oy = Y0 - (c.kf[1] + SZ - 1), oz = Z0 - (c.kf[2] + SZ - 1);
     constexpr int NT = TX * TY * (TZ / R);
-    for (int t = threadIdx.x; t < LX * LY * LZ; t += NT) {
-        const int lx = t % LX, ly = (t / LX) % LY, lz = t / (LX * LY);
-        lds[t] = q[((size_t)modp(oz + lz, Mz) * My + modp(oy + ly, My)) * Mx + modp(ox + lx, Mx)];
+    constexpr int LYU = TY + SZ - 1; // rows actually used
+    {
+        // staging: half a wave per (z, y) row of the tile, lanes along x; the periodic wrap is done once per row
+        // and by conditional subtraction along x (no integer division in the loop)
+        static_assert(LX <= 64, "a row is staged by half a wave in at most two steps");
+        const int half = threadIdx.x >> 5, hl = threadIdx.x & 31;
+        const int gx0 = modp(ox + hl, Mx), gx1 = modp(ox + hl + 32, Mx);
+        constexpr int NH = NT / 32, BATCH = 8; // rows per pass: all their loads are issued before the first store
+        for (int row0 = half; row0 < LYU * LZ; row0 += NH * BATCH) {
+            double v0[BATCH], v1[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                const int row = row0 + k * NH;
+                v0[k] = v1[k] = 0.0;
+                if (row < LYU * LZ) {
+                    const int ly = row % LYU, lz = row / LYU;
+                    const size_t rowbase = ((size_t)modp(oz + lz, Mz) * My + modp(oy + ly, My)) * Mx;
+                    if (hl < LX) v0[k] = q[rowbase + gx0];
+                    if (LX > 32 && hl + 32 < LX) v1[k] = q[rowbase + gx1];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; k++) {
+                const int row = row0 + k * NH;
+                if (row < LYU * LZ) {
+                    const int ly = row % LYU, lz = row / LYU;
+                    if (hl < LX) lds[(lz * LX + hl) * LY + ly] = v0[k];
+                    if (LX > 32 && hl + 32 < LX) lds[(lz * LX + hl + 32) * LY + ly] = v1[k];
+                }
+            }
+        }
     }
     __syncthreads();
     const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) % TY, tg = threadIdx.x / (TX * TY);
     constexpr int W = R + SZ - 1;
-    const int plane = LY * LX;
-    const double *col0 = lds + (size_t)(tg * R) * plane + (ty + syn - 1) * LX + (tx + sxn - 1);
+    constexpr int plane = LX * LY;
+    const double *col0 = lds + (tg * R) * plane + (tx + SZ - 1) * LY + (ty + SZ - 1);
     double acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.0;
-    double va[W], vb[W], ka[SZ], kb[SZ];
-    const int ntaps = sxn * syn;
+    double vc[W], kc[SZ]; // window and taps of the current (sx, sy)
 #pragma unroll
-    for (int w = 0; w < W; w++) va[w] = col0[w * plane];
+    for (int w = 0; w < W; w++) vc[w] = col0[w * plane];
 #pragma unroll
-    for (int z = 0; z < SZ; z++) ka[z] = Kt[z];
-    int sx = 0, sy = 0; // tap t = sy * sxn + sx
-    for (int t = 0; t < ntaps; t += 2) {
-        // fetch tap t + 1 into the b registers
-        int sx1 = sx + 1, sy1 = sy;
-        if (sx1 == sxn) { sx1 = 0; sy1++; }
-        const bool has1 = t + 1 < ntaps;
-        // The window and taps of tap t were fetched a whole block ago: wait for them now, before the next
-        // fetches are issued (scalar loads return out of order, so a later wait would have to be a full one
-        // and would expose the latency of the new fetches).
-        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const double *col = col0 - (has1 ? sy1 * LX + sx1 : 0);
-            const double *kk = Kt + (size_t)(has1 ? t + 1 : 0) * SZ;
+    for (int z = 0; z < SZ; z++) kc[z] = Kt[z];
+    for (int sy = 0; sy < SZ; sy++) {
+        const bool more = sy + 1 < SZ;
 #pragma unroll
-            for (int w = 0; w < W; w++) vb[w] = col[w * plane];
+        for (int sx = 0; sx < SZ; sx++) {
+            // The window (LDS) and the taps (scalar loads, wave-uniform) of this tap were requested a whole tap
+            // ago: wait for them now, before the next requests go out, so that those have the length of the
+            // FMA block below to arrive (scalar loads return out of order: any later wait would be a full one).
+            __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+            __builtin_amdgcn_sched_barrier(0);
+            double vn[W], kn[SZ];
+            {
+                const bool last = sx == SZ - 1;
+                const double *col = last ? col0 - (more ? sy + 1 : 0) : col0 - ((sx + 1) * LY + sy);
+                const double *kk = Kt + (size_t)(last ? (more ? (sy + 1) * SZ : 0) : sy * SZ + sx + 1) * SZ;
 #pragma unroll
-            for (int z = 0; z < SZ; z++) kb[z] = kk[z];
+                for (int w = 0; w < W; w++) vn[w] = col[w * plane];
+#pragma unroll
+                for (int z = 0; z < SZ; z++) kn[z] = kk[z];
+            }
+            __builtin_amdgcn_sched_barrier(0); // keep the requests above ahead of the FMAs below
+#pragma unroll
+            for (int z = 0; z < SZ; z++)
+#pragma unroll
+                for (int r = 0; r < R; r++) acc[r] = fma(kc[z], vc[r + SZ - 1 - z], acc[r]);
+#pragma unroll
+            for (int w = 0; w < W; w++) vc[w] = vn[w];
+#pragma unroll
+            for (int z = 0; z < SZ; z++) kc[z] = kn[z];
         }
-        __builtin_amdgcn_sched_barrier(0); // keep the fetches above ahead of the FMAs below
-#pragma unroll
-        for (int z = 0; z < SZ; z++)
-#pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = fma(ka[z], va[r + SZ - 1 - z], acc[r]);
-        if (!has1) break;
-        // fetch tap t + 2 into the a registers
-        int sx2 = sx1 + 1, sy2 = sy1;
-        if (sx2 == sxn) { sx2 = 0; sy2++; }
-        const bool has2 = t + 2 < ntaps;
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const double *col = col0 - (has2 ? sy2 * LX + sx2 : 0);
-            const double *kk = Kt + (size_t)(has2 ? t + 2 : 0) * SZ;
-#pragma unroll
-            for (int w = 0; w < W; w++) va[w] = col[w * plane];
-#pragma unroll
-            for (int z = 0; z < SZ; z++) ka[z] = kk[z];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int z = 0; z < SZ; z++)
-#pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = fma(kb[z], vb[r + SZ - 1 - z], acc[r]);
-        sx = sx2;
-        sy = sy2;
     }
     const int mx = X0 + tx, my = Y0 + ty;
     if (mx < Mx && my < My) {
@@ -1152,8 +1164,8 @@ static bool conv_multi_launch(hipStream_t st, ConvBatch &B) {
     int nblk = 0;
     for (int l = 0; l < B.n; l++) {
         const ConvArgs &c = B.c[l];
-        if (c.ks[2] != SZ) return false;
-        const int LX = TX + c.ks[0] - 1, LY = TY + c.ks[1] - 1, LZ = TZ + SZ - 1;
+        if (c.ks[0] != SZ || c.ks[1] != SZ || c.ks[2] != SZ) return false;
+        const int LX = TX + SZ - 1, LY = ((TY + SZ - 1 + 1) / 4) * 4 + 2, LZ = TZ + SZ - 1;
         bytes = std::max(bytes, sizeof(double) * (size_t)LX * LY * LZ);
         B.ntx[l] = (c.M[0] + TX - 1) / TX;
         B.nty[l] = (c.M[1] + TY - 1) / TY;
