@@ -1132,8 +1132,12 @@ __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
                 const bool last = sx == SZ - 1;
                 const double *col = last ? col0 - (more ? sy + 1 : 0) : col0 - ((sx + 1) * LY + sy);
                 const double *kk = Kt + (size_t)(last ? (more ? (sy + 1) * SZ : 0) : sy * SZ + sx + 1) * SZ;
+                // two base addresses, so that every read of the window has its plane offset in the instruction
+                // (the 16-bit offset field reaches 12 planes of this tile)
+                constexpr int WH = (W + 1) / 2;
+                const double *colb = col + WH * plane;
 #pragma unroll
-                for (int w = 0; w < W; w++) vn[w] = col[w * plane];
+                for (int w = 0; w < W; w++) vn[w] = w < WH ? col[w * plane] : colb[(w - WH) * plane];
 #pragma unroll
                 for (int z = 0; z < SZ; z++) kn[z] = kk[z];
             }
