@@ -1053,7 +1053,7 @@ bool launch_conv_tiled(hipStream_t st, const double *q, const double *Kt, const 
 // tile and feeds R * SZ FMAs whose stencil taps are wave-uniform (scalar loads).  With one wave per SIMD (the
 // tile takes almost all of the LDS) nothing else hides latency, so the window and the taps of the next
 // (sx, sy) are requested before the FMAs of the current one are issued.
-template <int SZ, int R, int TX, int TY, int TZ>
+template <int SZ, int R, int TX, int TY, int TZ, int CH>
 __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
     extern __shared__ double lds[];
     int lev = 0;
@@ -1065,91 +1065,104 @@ __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
     const int ntx = B.ntx[lev], nty = B.nty[lev];
     const int Mx = c.M[0], My = c.M[1], Mz = c.M[2];
     // LDS tile [z][x][y], y fastest, row length LY = 2 mod 4 doubles: the 16 x 2 (x, y) lanes of a half wave then
-    // fall on 64 different banks, so a window read costs its two LDS cycles and no more
-    constexpr int LX = TX + SZ - 1, LY = ((TY + SZ - 1 + 1) / 4) * 4 + 2, LZ = TZ + SZ - 1;
-    static_assert(LY >= TY + SZ - 1, "row padding");
+    // fall on 64 different banks, so a window read costs its two LDS cycles and no more.  The tile holds the y
+    // rows of CH consecutive sy at a time (CH = SZ when the whole halo fits the LDS; wider stencils restage).
+    constexpr int CHR = CH < SZ ? CH : SZ;
+    constexpr int LX = TX + SZ - 1, LY = ((TY + CHR - 1 + 1) / 4) * 4 + 2, LZ = TZ + SZ - 1;
+    static_assert(LY >= TY + CHR - 1, "row padding");
+    static_assert(LX <= 64, "a row is staged by half a wave in at most two steps");
     const int bid = blockIdx.x - B.blk0[lev];
     const int bx = bid % ntx, by = (bid / ntx) % nty, bz = bid / (ntx * nty);
     const int X0 = bx * TX, Y0 = by * TY, Z0 = c.z0 + bz * TZ;
     const int ox = X0 - (c.kf[0] + SZ - 1), oy = Y0 - (c.kf[1] + SZ - 1), oz = Z0 - (c.kf[2] + SZ - 1);
     constexpr int NT = TX * TY * (TZ / R);
-    constexpr int LYU = TY + SZ - 1; // rows actually used
-    {
-        // staging: half a wave per (z, y) row of the tile, lanes along x; the periodic wrap is done once per row
-        // and by conditional subtraction along x (no integer division in the loop)
-        static_assert(LX <= 64, "a row is staged by half a wave in at most two steps");
-        const int half = threadIdx.x >> 5, hl = threadIdx.x & 31;
-        const int gx0 = modp(ox + hl, Mx), gx1 = modp(ox + hl + 32, Mx);
-        constexpr int NH = NT / 32, BATCH = 8; // rows per pass: all their loads are issued before the first store
-        for (int row0 = half; row0 < LYU * LZ; row0 += NH * BATCH) {
-            double v0[BATCH], v1[BATCH];
-#pragma unroll
-            for (int k = 0; k < BATCH; k++) {
-                const int row = row0 + k * NH;
-                v0[k] = v1[k] = 0.0;
-                if (row < LYU * LZ) {
-                    const int ly = row % LYU, lz = row / LYU;
-                    const size_t rowbase = ((size_t)modp(oz + lz, Mz) * My + modp(oy + ly, My)) * Mx;
-                    if (hl < LX) v0[k] = q[rowbase + gx0];
-                    if (LX > 32 && hl + 32 < LX) v1[k] = q[rowbase + gx1];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < BATCH; k++) {
-                const int row = row0 + k * NH;
-                if (row < LYU * LZ) {
-                    const int ly = row % LYU, lz = row / LYU;
-                    if (hl < LX) lds[(lz * LX + hl) * LY + ly] = v0[k];
-                    if (LX > 32 && hl + 32 < LX) lds[(lz * LX + hl + 32) * LY + ly] = v1[k];
-                }
-            }
-        }
-    }
-    __syncthreads();
     const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) % TY, tg = threadIdx.x / (TX * TY);
     constexpr int W = R + SZ - 1;
     constexpr int plane = LX * LY;
-    const double *col0 = lds + (tg * R) * plane + (tx + SZ - 1) * LY + (ty + SZ - 1);
+    const int half = threadIdx.x >> 5, hl = threadIdx.x & 31;
+    const int gx0 = modp(ox + hl, Mx), gx1 = modp(ox + hl + 32, Mx);
     double acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.0;
-    double vc[W], kc[SZ]; // window and taps of the current (sx, sy)
+    for (int c0 = 0; c0 < SZ; c0 += CHR) {
+        const int nch = min(CHR, SZ - c0); // this pass applies the taps sy in [c0, c0 + nch)
+        const int ys = SZ - c0 - nch;      // first y row (of the full halo) they touch
+        const int rows = TY + nch - 1;
+        if (c0 > 0) __syncthreads();
+        {
+            // staging: half a wave per (z, y) row of the tile, lanes along x; the periodic wrap is done once per
+            // row (no integer division per element), and the loads of 8 rows are issued before the first store
+            constexpr int NH = NT / 32, BATCH = 8;
+            int ly = half, lz = 0; // row = lz * rows + ly, advanced by NH per step
+            while (ly >= rows) { ly -= rows; lz++; }
+            while (lz < LZ) {
+                double v0[BATCH], v1[BATCH];
+                int sly[BATCH], slz[BATCH];
 #pragma unroll
-    for (int w = 0; w < W; w++) vc[w] = col0[w * plane];
+                for (int k = 0; k < BATCH; k++) {
+                    sly[k] = ly; slz[k] = lz;
+                    v0[k] = v1[k] = 0.0;
+                    if (lz < LZ) {
+                        const size_t rowbase = ((size_t)modp(oz + lz, Mz) * My + modp(oy + ys + ly, My)) * Mx;
+                        if (hl < LX) v0[k] = q[rowbase + gx0];
+                        if (LX > 32 && hl + 32 < LX) v1[k] = q[rowbase + gx1];
+                    }
+                    ly += NH;
+                    while (ly >= rows) { ly -= rows; lz++; }
+                }
 #pragma unroll
-    for (int z = 0; z < SZ; z++) kc[z] = Kt[z];
-    for (int sy = 0; sy < SZ; sy++) {
-        const bool more = sy + 1 < SZ;
-#pragma unroll
-        for (int sx = 0; sx < SZ; sx++) {
-            // The window (LDS) and the taps (scalar loads, wave-uniform) of this tap were requested a whole tap
-            // ago: wait for them now, before the next requests go out, so that those have the length of the
-            // FMA block below to arrive (scalar loads return out of order: any later wait would be a full one).
-            __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
-            __builtin_amdgcn_sched_barrier(0);
-            double vn[W], kn[SZ];
-            {
-                const bool last = sx == SZ - 1;
-                const double *col = last ? col0 - (more ? sy + 1 : 0) : col0 - ((sx + 1) * LY + sy);
-                const double *kk = Kt + (size_t)(last ? (more ? (sy + 1) * SZ : 0) : sy * SZ + sx + 1) * SZ;
-                // two base addresses, so that every read of the window has its plane offset in the instruction
-                // (the 16-bit offset field reaches 12 planes of this tile)
-                constexpr int WH = (W + 1) / 2;
-                const double *colb = col + WH * plane;
-#pragma unroll
-                for (int w = 0; w < W; w++) vn[w] = w < WH ? col[w * plane] : colb[(w - WH) * plane];
-#pragma unroll
-                for (int z = 0; z < SZ; z++) kn[z] = kk[z];
+                for (int k = 0; k < BATCH; k++) {
+                    if (slz[k] < LZ) {
+                        if (hl < LX) lds[(slz[k] * LX + hl) * LY + sly[k]] = v0[k];
+                        if (LX > 32 && hl + 32 < LX) lds[(slz[k] * LX + hl + 32) * LY + sly[k]] = v1[k];
+                    }
+                }
             }
-            __builtin_amdgcn_sched_barrier(0); // keep the requests above ahead of the FMAs below
+        }
+        __syncthreads();
+        // window of tap (sx, sy): colc - (sx * LY + sy)
+        const double *colc = lds + (tg * R) * plane + (tx + SZ - 1) * LY + (ty + c0 + nch - 1);
+        double vc[W], kc[SZ]; // window and taps of the current (sx, sy)
+        {
+            const double *col = colc - c0;
+            const double *kk = Kt + (size_t)c0 * SZ * SZ;
 #pragma unroll
-            for (int z = 0; z < SZ; z++)
+            for (int w = 0; w < W; w++) vc[w] = col[w * plane];
 #pragma unroll
-                for (int r = 0; r < R; r++) acc[r] = fma(kc[z], vc[r + SZ - 1 - z], acc[r]);
+            for (int z = 0; z < SZ; z++) kc[z] = kk[z];
+        }
+        for (int sy = c0; sy < c0 + nch; sy++) {
+            const bool more = sy + 1 < c0 + nch;
 #pragma unroll
-            for (int w = 0; w < W; w++) vc[w] = vn[w];
+            for (int sx = 0; sx < SZ; sx++) {
+                // The window (LDS) and the taps (wave-uniform loads) of this tap were requested a whole tap ago:
+                // wait for them now, before the next requests go out, so that those have the length of the FMA
+                // block below to arrive.
+                __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+                __builtin_amdgcn_sched_barrier(0);
+                double vn[W], kn[SZ];
+                {
+                    const bool last = sx == SZ - 1;
+                    // after the last tap of a pass there is nothing to fetch: any valid address will do
+                    const double *col = last ? colc - (more ? sy + 1 : sy) : colc - ((sx + 1) * LY + sy);
+                    const double *kk = Kt + (size_t)(last ? (more ? (sy + 1) * SZ : sy * SZ) : sy * SZ + sx + 1) * SZ;
+                    constexpr int WH = (W + 1) / 2;
+                    const double *colb = col + WH * plane;
 #pragma unroll
-            for (int z = 0; z < SZ; z++) kc[z] = kn[z];
+                    for (int w = 0; w < W; w++) vn[w] = w < WH ? col[w * plane] : colb[(w - WH) * plane];
+#pragma unroll
+                    for (int z = 0; z < SZ; z++) kn[z] = kk[z];
+                }
+                __builtin_amdgcn_sched_barrier(0); // keep the requests above ahead of the FMAs below
+#pragma unroll
+                for (int z = 0; z < SZ; z++)
+#pragma unroll
+                    for (int r = 0; r < R; r++) acc[r] = fma(kc[z], vc[r + SZ - 1 - z], acc[r]);
+#pragma unroll
+                for (int w = 0; w < W; w++) vc[w] = vn[w];
+#pragma unroll
+                for (int z = 0; z < SZ; z++) kc[z] = kn[z];
+            }
         }
     }
     const int mx = X0 + tx, my = Y0 + ty;
@@ -1162,45 +1175,49 @@ __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
     }
 }
 
-template <int SZ, int R, int TX, int TY, int TZ>
+template <int SZ, int R, int TX, int TY, int TZ, int CH>
 static bool conv_multi_launch(hipStream_t st, ConvBatch &B) {
-    size_t bytes = 0;
+    constexpr int CHR = CH < SZ ? CH : SZ;
+    constexpr int LX = TX + SZ - 1, LY = ((TY + CHR - 1 + 1) / 4) * 4 + 2, LZ = TZ + SZ - 1;
+    constexpr size_t bytes = sizeof(double) * (size_t)LX * LY * LZ;
+    static_assert(bytes <= 160 * 1024, "tile exceeds the LDS");
     int nblk = 0;
     for (int l = 0; l < B.n; l++) {
         const ConvArgs &c = B.c[l];
         if (c.ks[0] != SZ || c.ks[1] != SZ || c.ks[2] != SZ) return false;
-        const int LX = TX + SZ - 1, LY = ((TY + SZ - 1 + 1) / 4) * 4 + 2, LZ = TZ + SZ - 1;
-        bytes = std::max(bytes, sizeof(double) * (size_t)LX * LY * LZ);
         B.ntx[l] = (c.M[0] + TX - 1) / TX;
         B.nty[l] = (c.M[1] + TY - 1) / TY;
         B.blk0[l] = nblk;
         nblk += B.ntx[l] * B.nty[l] * ((c.nz + TZ - 1) / TZ);
     }
     B.blk0[B.n] = nblk;
-    if (bytes > 160 * 1024 || nblk == 0) return false;
-    auto kern = k_conv_multi<SZ, R, TX, TY, TZ>;
+    if (nblk == 0) return false;
+    auto kern = k_conv_multi<SZ, R, TX, TY, TZ, CH>;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(TX * TY * (TZ / R)), bytes, st, B);
     return true;
 }
 
+// tile 16 x 8 x 16 outputs, 8 per thread; CH = rows of sy per staging pass, the most the 160 KB of LDS hold
 bool launch_conv_multi(hipStream_t st, ConvBatch &B) {
     if (B.n < 1) return false;
     switch (B.c[0].ks[2]) {
-#define CASE_SZ(S) \
-    case S: return conv_multi_launch<S, 8, 16, 8, 16>(st, B);
-        CASE_SZ(7)
-        CASE_SZ(9)
-        CASE_SZ(11)
-        CASE_SZ(13)
-        CASE_SZ(15)
-        CASE_SZ(17)
-        CASE_SZ(19)
-#undef CASE_SZ
+    case 7: return conv_multi_launch<7, 8, 16, 8, 16, 7>(st, B);
+    case 9: return conv_multi_launch<9, 8, 16, 8, 16, 9>(st, B);
+    case 11: return conv_multi_launch<11, 8, 16, 8, 16, 11>(st, B);
+    case 13: return conv_multi_launch<13, 8, 16, 8, 16, 13>(st, B);
+    case 15: return conv_multi_launch<15, 8, 16, 8, 16, 15>(st, B);
+    case 17: return conv_multi_launch<17, 8, 16, 8, 16, 11>(st, B); // 32 x 18 x 32 doubles
+    case 19: return conv_multi_launch<19, 8, 16, 8, 16, 7>(st, B);  // 34 x 14 x 34
+    case 21: return conv_multi_launch<21, 8, 16, 8, 16, 7>(st, B);  // 36 x 14 x 36
+    case 23: return conv_multi_launch<23, 8, 16, 8, 16, 7>(st, B);  // 38 x 14 x 38
     default:
         return false;
     }

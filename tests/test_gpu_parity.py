@@ -206,6 +206,27 @@ def test_anterpolation_tiled(msm, torch, p, M):
     sp.close()
 
 
+@pytest.mark.parametrize("abar,p", [(4.5, 4), (5.0, 6), (5.5, 4), (6.0, 4)])
+def test_wide_stencils(msm, torch, abar, p):
+    """Stencils wider than the LDS tile's full halo (17..23 taps per axis) are applied in several staging
+    passes by the multi-level convolution kernel: grids and totals against the oracle."""
+    N, A = 20000, (1.0, 1.0, 1.0)
+    r, q = O.neutral_system(N, A, seed=31)
+    desc = msm.plan_auto(N, A, p, 10, abar, 2)
+    eng = msm.Engine(desc)
+    sizes = [eng.stencil(l)[0].shape[0] for l in range(desc.L)]
+    assert sizes[0] >= 17, sizes
+    sp = spec_for(desc)
+    ref = sp.eval(r, q)
+    en, acc = eng.eval(r, q)
+    for l in range(desc.L):
+        assert grid_err(eng.grid(msm.capi.GRID_E, l), sp.grid("e", l)) < TOL, (l, sizes)
+    assert np.abs(en - ref["energies"]).max() < TOL * np.abs(ref["energies"][:6]).max()
+    assert rel_rms(acc.cpu().numpy(), ref["acc"]) < TOL
+    eng.close()
+    sp.close()
+
+
 def test_conventions(msm, torch):
     """ACC_LITERAL = msmLibrary.c:168-176 / msmPeriodic.c:1158 weighting, ACC_FORCE = -q_i * gradient."""
     N, A = 2500, (1.0, 1.0, 1.0)
