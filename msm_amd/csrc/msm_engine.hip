@@ -71,6 +71,8 @@ struct msm_amd_handle {
     int *tile_used = nullptr;
     bool anterp_tiled = false;
     int opt_anterp_tiled = 1;
+    int opt_transfer_fused = 0;              // 0 separable passes (faster at every size measured), 1 fused, 2 fused up to opt_transfer_fused_max fine nodes
+    long opt_transfer_fused_max = 1L << 30;
 };
 
 static int g_mode = MSM_AMD_MODE_AUTO;
@@ -381,6 +383,8 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "conv_tiled")) { h->opt_conv_tiled = value; return MSM_AMD_OK; }
     if (!strcmp(key, "conv_small")) { h->opt_conv_small = value; return MSM_AMD_OK; }
     if (!strcmp(key, "anterp_tiled")) { h->opt_anterp_tiled = value; return MSM_AMD_OK; }
+    if (!strcmp(key, "transfer_fused")) { h->opt_transfer_fused = value; return MSM_AMD_OK; }
+    if (!strcmp(key, "transfer_fused_max")) { h->opt_transfer_fused_max = value; return MSM_AMD_OK; }
     set_error("unknown option %s", key);
     return MSM_AMD_EINVAL;
 }
@@ -498,20 +502,44 @@ static void convolve_level(msm_amd_handle *h, int l, const double *q, double *e,
     conv_untiled(h, q, h->dK[l], h->hp.Ml[l], S.size, S.first, e, z0, nz);
 }
 
+// Level transfers l <-> l+1.  One fused kernel when the grids are small (launch-bound), three separable passes
+// through the scratch grids when they are large; both give the same bits.
+static bool transfer_fused(const msm_amd_handle *h, int l) {
+    const long n = (long)h->hp.Ml[l][0] * h->hp.Ml[l][1] * h->hp.Ml[l][2];
+    return h->opt_transfer_fused == 1 || (h->opt_transfer_fused == 2 && n <= h->opt_transfer_fused_max);
+}
+static void restrict_level(msm_amd_handle *h, int l, const double *fine, double *coarse) {
+    const int p = h->hp.d.p;
+    int m0[3] = {h->hp.Ml[l][0], h->hp.Ml[l][1], h->hp.Ml[l][2]};
+    if (transfer_fused(h, l)) { launch_restrict3(h->stream, fine, coarse, m0, p, h->hp.J); return; }
+    launch_restrict_axis(h->stream, fine, h->tmpA, m0, 0, p, h->hp.J);
+    int m1[3] = {m0[0] / 2, m0[1], m0[2]};
+    launch_restrict_axis(h->stream, h->tmpA, h->tmpB, m1, 1, p, h->hp.J);
+    int m2[3] = {m0[0] / 2, m0[1] / 2, m0[2]};
+    launch_restrict_axis(h->stream, h->tmpB, coarse, m2, 2, p, h->hp.J);
+}
+static void prolong_level_add(msm_amd_handle *h, int l, const double *coarse, double *fine) {
+    const int p = h->hp.d.p;
+    if (transfer_fused(h, l)) {
+        int m0[3] = {h->hp.Ml[l][0], h->hp.Ml[l][1], h->hp.Ml[l][2]};
+        launch_prolong3_add(h->stream, coarse, fine, m0, p, h->hp.J);
+        return;
+    }
+    int c0[3] = {h->hp.Ml[l + 1][0], h->hp.Ml[l + 1][1], h->hp.Ml[l + 1][2]};
+    launch_prolong_axis(h->stream, coarse, h->tmpB, c0, 2, p, h->hp.J, 0);
+    int c1[3] = {c0[0], c0[1], c0[2] * 2};
+    launch_prolong_axis(h->stream, h->tmpB, h->tmpA, c1, 1, p, h->hp.J, 0);
+    int c2[3] = {c0[0], c0[1] * 2, c0[2] * 2};
+    launch_prolong_axis(h->stream, h->tmpA, fine, c2, 0, p, h->hp.J, 1);
+}
+
 extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
     if (!h) return MSM_AMD_EINVAL;
     const msm_amd_plan_desc &d = h->hp.d;
     const int L = d.L, p = d.p;
     hipStream_t st = h->stream;
     mark(h, T_RES);
-    for (int l = 0; l + 1 < L; l++) {
-        int m0[3] = {h->hp.Ml[l][0], h->hp.Ml[l][1], h->hp.Ml[l][2]};
-        launch_restrict_axis(st, h->gq[l], h->tmpA, m0, 0, p, h->hp.J);
-        int m1[3] = {m0[0] / 2, m0[1], m0[2]};
-        launch_restrict_axis(st, h->tmpA, h->tmpB, m1, 1, p, h->hp.J);
-        int m2[3] = {m0[0] / 2, m0[1] / 2, m0[2]};
-        launch_restrict_axis(st, h->tmpB, h->gq[l + 1], m2, 2, p, h->hp.J);
-    }
+    for (int l = 0; l + 1 < L; l++) restrict_level(h, l, h->gq[l], h->gq[l + 1]);
     mark(h, T_CONV);
     // plane ranges to convolve per level: everything, except on a slab rank's level 0, where the potentials are
     // needed on the owned planes plus p/2 planes either side (interpolation support) and the other planes of
@@ -572,14 +600,7 @@ extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
         }
     }
     mark(h, T_PRO);
-    for (int l = L - 2; l >= 0; l--) {
-        int c0[3] = {h->hp.Ml[l + 1][0], h->hp.Ml[l + 1][1], h->hp.Ml[l + 1][2]};
-        launch_prolong_axis(st, h->ge[l + 1], h->tmpB, c0, 2, p, h->hp.J, 0);
-        int c1[3] = {c0[0], c0[1], c0[2] * 2};
-        launch_prolong_axis(st, h->tmpB, h->tmpA, c1, 1, p, h->hp.J, 0);
-        int c2[3] = {c0[0], c0[1] * 2, c0[2] * 2};
-        launch_prolong_axis(st, h->tmpA, h->ge[l], c2, 0, p, h->hp.J, 1);
-    }
+    for (int l = L - 2; l >= 0; l--) prolong_level_add(h, l, h->ge[l + 1], h->ge[l]);
     HIPCHK(hipGetLastError());
     return MSM_AMD_OK;
 }
@@ -791,23 +812,13 @@ extern "C" int msm_amd_copy_wprime(msm_amd_handle *h, double *host_out, int *len
 }
 extern "C" int msm_amd_op_restrict(msm_amd_handle *h, int l, const double *d_fine, double *d_coarse) {
     if (!h || l < 0 || l + 1 >= h->hp.d.L) { set_error("op_restrict: level out of range"); return MSM_AMD_EINVAL; }
-    int m0[3] = {h->hp.Ml[l][0], h->hp.Ml[l][1], h->hp.Ml[l][2]};
-    launch_restrict_axis(h->stream, d_fine, h->tmpA, m0, 0, h->hp.d.p, h->hp.J);
-    int m1[3] = {m0[0] / 2, m0[1], m0[2]};
-    launch_restrict_axis(h->stream, h->tmpA, h->tmpB, m1, 1, h->hp.d.p, h->hp.J);
-    int m2[3] = {m0[0] / 2, m0[1] / 2, m0[2]};
-    launch_restrict_axis(h->stream, h->tmpB, d_coarse, m2, 2, h->hp.d.p, h->hp.J);
+    restrict_level(h, l, d_fine, d_coarse);
     HIPCHK(hipGetLastError());
     return MSM_AMD_OK;
 }
 extern "C" int msm_amd_op_prolong_add(msm_amd_handle *h, int l, const double *d_coarse, double *d_fine) {
     if (!h || l < 0 || l + 1 >= h->hp.d.L) { set_error("op_prolong_add: level out of range"); return MSM_AMD_EINVAL; }
-    int c0[3] = {h->hp.Ml[l + 1][0], h->hp.Ml[l + 1][1], h->hp.Ml[l + 1][2]};
-    launch_prolong_axis(h->stream, d_coarse, h->tmpB, c0, 2, h->hp.d.p, h->hp.J, 0);
-    int c1[3] = {c0[0], c0[1], c0[2] * 2};
-    launch_prolong_axis(h->stream, h->tmpB, h->tmpA, c1, 1, h->hp.d.p, h->hp.J, 0);
-    int c2[3] = {c0[0], c0[1] * 2, c0[2] * 2};
-    launch_prolong_axis(h->stream, h->tmpA, d_fine, c2, 0, h->hp.d.p, h->hp.J, 1);
+    prolong_level_add(h, l, d_coarse, d_fine);
     HIPCHK(hipGetLastError());
     return MSM_AMD_OK;
 }

@@ -128,6 +128,9 @@ void launch_interp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &s
 void launch_interp(hipStream_t st, const double4 *ps_grid, const int *order, int N, const SplineParams &sp,
                    const double *egrid, int index_shift, double *acc);
 // one axis of the separable restriction: out has the axis halved.  J[0..p/2]
+// the three axis passes of a level transfer fused (same sums, same order); fine grid Mf, coarse grid Mf/2
+void launch_restrict3(hipStream_t st, const double *fine, double *coarse, const int Mf[3], int p, const double J[4]);
+void launch_prolong3_add(hipStream_t st, const double *coarse, double *fine, const int Mf[3], int p, const double J[4]);
 void launch_restrict_axis(hipStream_t st, const double *in, double *out, const int Min[3], int axis, int p, const double J[4]);
 // one axis of the separable prolongation: out has the axis doubled; accumulate != 0 adds into out
 void launch_prolong_axis(hipStream_t st, const double *in, double *out, const int Min[3], int axis, int p, const double J[4],
