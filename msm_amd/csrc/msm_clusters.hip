@@ -13,6 +13,8 @@
 
 #include "msm_amd.h"
 
+#include <algorithm>
+
 namespace msm {
 
 #define CL_NOSHIFT 13          // code (px+1) + 3 (py+1) + 9 (pz+1) of the zero image shift
@@ -391,21 +393,12 @@ __global__ __launch_bounds__(256) void k_pair_clusters(ClusterGeom g, ClusterBuf
     cl_finish(I, pp, jj, icl, u, fx, fy, fz, acc, epart, lane);
 }
 
-// The same sum without lists: the wave enumerates its candidates and evaluates each surviving cluster pair on
-// the spot.  With FALLBACK it only takes the clusters whose list did not fit.
-template <int P, bool FALLBACK>
-__global__ __launch_bounds__(256) void k_pair_clusters_direct(ClusterGeom g, ClusterBuffers b, PairParams pp, double a,
-                                                              double *__restrict__ acc, double *__restrict__ epart) {
-    const int lane = threadIdx.x & 63, ii = lane >> 3, jj = lane & 7;
-    const int blk = xcd_remap(blockIdx.x, gridDim.x);
-    const int icl = __builtin_amdgcn_readfirstlane(blk * 4 + (threadIdx.x >> 6));
-    if (icl >= g.max_clusters) return;
-    const int ncl = b.clstart[g.ncols];
-    if (icl >= ncl) {
-        if (!FALLBACK && lane == 0) epart[icl] = 0.0;
-        return;
-    }
-    if (FALLBACK && b.n0[icl] >= 0) return;
+// The same sum for one cluster without a list: the wave enumerates its candidates and evaluates each surviving
+// cluster pair on the spot.
+template <int P>
+__device__ __forceinline__ void direct_one_cluster(const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double a,
+                                                   double *__restrict__ acc, double *__restrict__ epart, int icl, int lane) {
+    const int ii = lane >> 3, jj = lane & 7;
     const LaneI I = load_lane_i(g, b, pp, icl, ii);
     if (!__ballot(I.owned)) {
         if (lane == 0) epart[icl] = 0.0;
@@ -435,13 +428,46 @@ __global__ __launch_bounds__(256) void k_pair_clusters_direct(ClusterGeom g, Clu
     cl_finish(I, pp, jj, icl, u, fx, fy, fz, acc, epart, lane);
 }
 
+// every cluster list-free (A/B variant)
+template <int P>
+__global__ __launch_bounds__(256) void k_pair_clusters_direct(ClusterGeom g, ClusterBuffers b, PairParams pp, double a,
+                                                              double *__restrict__ acc, double *__restrict__ epart) {
+    const int lane = threadIdx.x & 63;
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int icl = __builtin_amdgcn_readfirstlane(blk * 4 + (threadIdx.x >> 6));
+    if (icl >= g.max_clusters) return;
+    if (icl >= b.clstart[g.ncols]) {
+        if (lane == 0) epart[icl] = 0.0;
+        return;
+    }
+    direct_one_cluster<P>(g, b, pp, a, acc, epart, icl, lane);
+}
+
+// only the clusters whose list overflowed (n0 < 0): a small fixed grid scans the list lengths, 64 per wave step,
+// so that the usual case (none) costs a few microseconds
+template <int P>
+__global__ __launch_bounds__(256) void k_pair_clusters_overflow(ClusterGeom g, ClusterBuffers b, PairParams pp, double a,
+                                                                double *__restrict__ acc, double *__restrict__ epart) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int ncl = b.clstart[g.ncols];
+    for (int base = wave * 64; base < ncl; base += nwaves * 64) {
+        unsigned long long m = __ballot(base + lane < ncl && b.n0[base + lane] < 0);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            direct_one_cluster<P>(g, b, pp, a, acc, epart, base + l, lane);
+        }
+    }
+}
+
 void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double *acc,
                           double *epart, int variant, hipEvent_t *ev) {
     const double a = sqrt(pp.a2);
     const int nblk = (g.max_clusters + 3) / 4;
     if (variant == 1) {
-        if (pp.p == 4) hipLaunchKernelGGL((k_pair_clusters_direct<4, false>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart);
-        else hipLaunchKernelGGL((k_pair_clusters_direct<6, false>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart);
+        if (pp.p == 4) hipLaunchKernelGGL((k_pair_clusters_direct<4>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart);
+        else hipLaunchKernelGGL((k_pair_clusters_direct<6>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart);
         return;
     }
     hipLaunchKernelGGL(k_cl_list, dim3(nblk), dim3(256), 0, st, g, b, a, pp.a2, pp.n_owned);
@@ -456,13 +482,13 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
         else if (variant == 3) LAUNCH_PC(4, false, 2);
         else if (variant == 4) LAUNCH_PC(4, false, 8);
         else LAUNCH_PC(4, false, 4);
-        hipLaunchKernelGGL((k_pair_clusters_direct<4, true>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart);
+        hipLaunchKernelGGL((k_pair_clusters_overflow<4>), dim3(std::min(nblk, 256)), dim3(256), 0, st, g, b, pp, a, acc, epart);
     } else {
         if (variant == 2) LAUNCH_PC(6, true, 4);
         else if (variant == 3) LAUNCH_PC(6, false, 2);
         else if (variant == 4) LAUNCH_PC(6, false, 8);
         else LAUNCH_PC(6, false, 4);
-        hipLaunchKernelGGL((k_pair_clusters_direct<6, true>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart);
+        hipLaunchKernelGGL((k_pair_clusters_overflow<6>), dim3(std::min(nblk, 256)), dim3(256), 0, st, g, b, pp, a, acc, epart);
     }
 #undef LAUNCH_PC
 }
