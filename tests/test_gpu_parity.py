@@ -404,6 +404,12 @@ def test_full_size_properties(msm, torch):
     # bitwise reproducible
     en2, acc2 = eng.eval(rd, qd)
     assert np.array_equal(en, en2) and np.array_equal(acc, acc2.cpu().numpy())
+    # the grid branch on a second stream beside the pair branch: same kernels, same order of every sum
+    eng.set_option("overlap", 1)
+    for _ in range(3):
+        en2, acc2 = eng.eval(rd, qd)
+        assert np.array_equal(en, en2) and np.array_equal(acc, acc2.cpu().numpy())
+    eng.set_option("overlap", 0)
     # the pair kernel variants agree at full size
     for v in (1, 2, 3, 4, 6, 5):
         eng.set_option("pair_variant", v)
