@@ -230,32 +230,37 @@ __global__ __launch_bounds__(256) void k_cl_list(ClusterGeom g, ClusterBuffers b
     if (icl >= ncl) return;
     // a cluster of halo copies only produces no output: no list needed (the pair kernels skip it the same way)
     if (!__ballot(lane < CL_G && b.order[(size_t)CL_G * icl + lane] < n_owned)) {
-        if (lane == 0) { b.n0[icl] = 0; b.n1[icl] = 0; }
+        if (lane == 0) { b.n0[icl] = 0; b.n1[icl] = 0; b.n2[icl] = 0; }
         return;
     }
     const double4 il = b.blo[icl], ih = b.bhi[icl];
     const IBox ib = {il.x, il.y, il.z, ih.x, ih.y, ih.z};
-    const int S = g.list_stride;
+    const int S = g.list_stride, MID = S / 2;
     int *__restrict__ L = b.list + (size_t)icl * S;
-    int n0 = 1, n1 = 0;
+    int nu = 1, nd = 0, ns = 0; // "up" (j > i, from the front, after the cluster itself), "down" (j < i, from the
+                                // middle), shifted (from the back)
     bool overflow = false;
     if (lane == 0) L[0] = icl;
     cl_enumerate(g, b, a, a2, ib, lane, [&](bool keep, int jcl, int code) {
         if (jcl == icl && code == CL_NOSHIFT) keep = false;
-        const bool k0 = keep && code == CL_NOSHIFT, k1 = keep && code != CL_NOSHIFT;
-        const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
-        const int c0 = __popcll(m0), c1 = __popcll(m1);
-        if (n0 + n1 + c0 + c1 > S) overflow = true;
+        const bool ku = keep && code == CL_NOSHIFT && jcl > icl, kd = keep && code == CL_NOSHIFT && jcl < icl;
+        const bool ks = keep && code != CL_NOSHIFT;
+        const unsigned long long mu = __ballot(ku), md = __ballot(kd), ms = __ballot(ks);
+        const int cu = __popcll(mu), cd = __popcll(md), cs = __popcll(ms);
+        if (nu + cu > MID || MID + nd + cd + ns + cs > S) overflow = true;
         else {
-            if (k0) L[n0 + lane_rank(m0)] = jcl;
-            if (k1) L[S - 1 - (n1 + lane_rank(m1))] = (int)((unsigned)jcl | ((unsigned)code << CL_CODE_SHIFT));
+            if (ku) L[nu + lane_rank(mu)] = jcl;
+            if (kd) L[MID + nd + lane_rank(md)] = jcl;
+            if (ks) L[S - 1 - (ns + lane_rank(ms))] = (int)((unsigned)jcl | ((unsigned)code << CL_CODE_SHIFT));
         }
-        n0 += c0;
-        n1 += c1;
+        nu += cu;
+        nd += cd;
+        ns += cs;
     });
     if (lane == 0) {
-        b.n0[icl] = overflow ? -1 : n0;
-        b.n1[icl] = n1;
+        b.n0[icl] = overflow ? -1 : nu;
+        b.n1[icl] = ns;
+        b.n2[icl] = nd;
     }
 }
 
@@ -296,6 +301,25 @@ __device__ __forceinline__ void cl_slot(double xi, double yi, double zi, const d
     const double g0 = ir - gam;
     const double s = fma(-(ir * ir), ir, dg);
     u = fma(qm, g0, u);
+    const double qs = qm * s;
+    fx = fma(qs, dx, fx);
+    fy = fma(qs, dy, fy);
+    fz = fma(qs, dz, fz);
+}
+
+// the same pair without the energy: a pair (i, j) listed from both sides needs its energy only once
+template <int P>
+__device__ __forceinline__ void cl_slot_force(double xi, double yi, double zi, const double4 &pj, const PairParams &pp, double &fx,
+                                              double &fy, double &fz) {
+    const double dx = xi - pj.x, dy = yi - pj.y, dz = zi - pj.z;
+    const double r2 = fma(dx, dx, fma(dy, dy, dz * dz));
+    const bool in = r2 < pp.a2;
+    const double qm = __hiloint2double(in ? __double2hiint(pj.w) : 0, __double2loint(pj.w));
+    const double ir = rsqrt_seeded(r2);
+    double dg = pp.cdr[P - 2];
+#pragma unroll
+    for (int k = P - 3; k >= 0; k--) dg = fma(dg, r2, pp.cdr[k]);
+    const double s = fma(-(ir * ir), ir, dg);
     const double qs = qm * s;
     fx = fma(qs, dx, fx);
     fy = fma(qs, dy, fy);
@@ -351,7 +375,11 @@ __device__ __forceinline__ void shift_of_code(const ClusterGeom &g, int code, do
 }
 
 // One wave per cluster i, lane = (ii, jj) = (lane / 8, lane % 8); walks the list built by k_cl_list.
-template <int P, bool SKIP, int U>
+// HALF (every particle is owned, i.e. no slab decomposition): the energy of an unshifted pair is taken, whole, where
+// j's cluster comes after i's ("up" entries) and skipped where it comes before ("down" entries, forces only: a
+// quarter fewer instructions); the cluster's own pairs and pairs through a periodic image count half from either
+// side.  Otherwise every listed pair counts half (a slab rank sees the other half on the neighbour's side).
+template <int P, bool HALF, int U>
 __global__ __launch_bounds__(256) void k_pair_clusters(ClusterGeom g, ClusterBuffers b, PairParams pp, double *__restrict__ acc,
                                                        double *__restrict__ epart) {
     const int lane = threadIdx.x & 63, ii = lane >> 3, jj = lane & 7;
@@ -363,41 +391,59 @@ __global__ __launch_bounds__(256) void k_pair_clusters(ClusterGeom g, ClusterBuf
         if (lane == 0) epart[icl] = 0.0;
         return;
     }
-    const int n0 = b.n0[icl], n1 = b.n1[icl];
-    if (n0 < 0) return; // list overflow: left to the direct kernel
+    const int nu = b.n0[icl], ns = b.n1[icl], nd = b.n2[icl];
+    if (nu < 0) return; // list overflow: left to the list-free kernel
     const LaneI I = load_lane_i(g, b, pp, icl, ii);
     if (!__ballot(I.owned)) {
         if (lane == 0) epart[icl] = 0.0;
         return;
     }
-    const int S = g.list_stride;
+    const int S = g.list_stride, MID = S / 2;
     const int *__restrict__ L = b.list + (size_t)icl * S;
     const double4 *__restrict__ pj = b.ps + jj;
-    double u = 0, fx = 0, fy = 0, fz = 0;
-    cl_slot<P, true>(I.x, I.y, I.z, pj[(size_t)CL_G * icl], pp, ii != jj, u, fx, fy, fz);
+    double u1 = 0, uh = 0, fx = 0, fy = 0, fz = 0; // u1: pairs counted whole, uh: pairs counted half
+    cl_slot<P, true>(I.x, I.y, I.z, pj[(size_t)CL_G * icl], pp, ii != jj, uh, fx, fy, fz);
     int e = 1;
-    for (; e + U <= n0; e += U) {
+    for (; e + U <= nu; e += U) {
         double4 qv[U];
 #pragma unroll
         for (int k = 0; k < U; k++) qv[k] = pj[(size_t)CL_G * L[e + k]];
 #pragma unroll
-        for (int k = 0; k < U; k++) cl_slot<P, false, SKIP>(I.x, I.y, I.z, qv[k], pp, true, u, fx, fy, fz);
+        for (int k = 0; k < U; k++) cl_slot<P, false>(I.x, I.y, I.z, qv[k], pp, true, HALF ? u1 : uh, fx, fy, fz);
     }
-    for (; e < n0; e++) cl_slot<P, false, SKIP>(I.x, I.y, I.z, pj[(size_t)CL_G * L[e]], pp, true, u, fx, fy, fz);
-    for (e = 0; e < n1; e++) {
+    for (; e < nu; e++) cl_slot<P, false>(I.x, I.y, I.z, pj[(size_t)CL_G * L[e]], pp, true, HALF ? u1 : uh, fx, fy, fz);
+    const int *__restrict__ Ld = L + MID;
+    e = 0;
+    for (; e + U <= nd; e += U) {
+        double4 qv[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) qv[k] = pj[(size_t)CL_G * Ld[e + k]];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            if (HALF) cl_slot_force<P>(I.x, I.y, I.z, qv[k], pp, fx, fy, fz);
+            else cl_slot<P, false>(I.x, I.y, I.z, qv[k], pp, true, uh, fx, fy, fz);
+        }
+    }
+    for (; e < nd; e++) {
+        const double4 q = pj[(size_t)CL_G * Ld[e]];
+        if (HALF) cl_slot_force<P>(I.x, I.y, I.z, q, pp, fx, fy, fz);
+        else cl_slot<P, false>(I.x, I.y, I.z, q, pp, true, uh, fx, fy, fz);
+    }
+    for (e = 0; e < ns; e++) {
         const int ent = L[S - 1 - e];
         double sx, sy, sz;
         shift_of_code(g, (int)((unsigned)ent >> CL_CODE_SHIFT), sx, sy, sz);
-        cl_slot<P, false, SKIP>(I.x - sx, I.y - sy, I.z - sz, pj[(size_t)CL_G * (ent & CL_JMASK)], pp, true, u, fx, fy, fz);
+        cl_slot<P, false>(I.x - sx, I.y - sy, I.z - sz, pj[(size_t)CL_G * (ent & CL_JMASK)], pp, true, uh, fx, fy, fz);
     }
-    cl_finish(I, pp, jj, icl, u, fx, fy, fz, acc, epart, lane);
+    cl_finish(I, pp, jj, icl, 2.0 * u1 + uh, fx, fy, fz, acc, epart, lane);
 }
 
 // The same sum for one cluster without a list: the wave enumerates its candidates and evaluates each surviving
 // cluster pair on the spot.
 template <int P>
 __device__ __forceinline__ void direct_one_cluster(const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double a,
-                                                   double *__restrict__ acc, double *__restrict__ epart, int icl, int lane) {
+                                                   double *__restrict__ acc, double *__restrict__ epart, int icl, int lane,
+                                                   bool half) {
     const int ii = lane >> 3, jj = lane & 7;
     const LaneI I = load_lane_i(g, b, pp, icl, ii);
     if (!__ballot(I.owned)) {
@@ -407,7 +453,9 @@ __device__ __forceinline__ void direct_one_cluster(const ClusterGeom &g, const C
     const double4 il = b.blo[icl], ih = b.bhi[icl];
     const IBox ib = {il.x, il.y, il.z, ih.x, ih.y, ih.z};
     const double4 *__restrict__ pj = b.ps + jj;
-    double u = 0, fx = 0, fy = 0, fz = 0;
+    // energy bookkeeping as in k_pair_clusters: with `half`, an unshifted pair counts whole on the side whose own
+    // cluster comes first, and not at all on the other side
+    double u1 = 0, uh = 0, unone = 0, fx = 0, fy = 0, fz = 0;
     cl_enumerate(g, b, a, pp.a2, ib, lane, [&](bool keep, int jcl, int code) {
         unsigned long long m = __ballot(keep);
         while (m) {
@@ -416,22 +464,22 @@ __device__ __forceinline__ void direct_one_cluster(const ClusterGeom &g, const C
             const int j = __builtin_amdgcn_readlane(jcl, l), cd = __builtin_amdgcn_readlane(code, l);
             const double4 q = pj[(size_t)CL_G * j];
             if (cd == CL_NOSHIFT) {
-                if (j == icl) cl_slot<P, true>(I.x, I.y, I.z, q, pp, ii != jj, u, fx, fy, fz);
-                else cl_slot<P, false>(I.x, I.y, I.z, q, pp, true, u, fx, fy, fz);
+                if (j == icl) cl_slot<P, true>(I.x, I.y, I.z, q, pp, ii != jj, uh, fx, fy, fz);
+                else cl_slot<P, false>(I.x, I.y, I.z, q, pp, true, !half ? uh : (j > icl ? u1 : unone), fx, fy, fz);
             } else {
                 double sx, sy, sz;
                 shift_of_code(g, cd, sx, sy, sz);
-                cl_slot<P, false>(I.x - sx, I.y - sy, I.z - sz, q, pp, true, u, fx, fy, fz);
+                cl_slot<P, false>(I.x - sx, I.y - sy, I.z - sz, q, pp, true, uh, fx, fy, fz);
             }
         }
     });
-    cl_finish(I, pp, jj, icl, u, fx, fy, fz, acc, epart, lane);
+    cl_finish(I, pp, jj, icl, 2.0 * u1 + uh, fx, fy, fz, acc, epart, lane);
 }
 
 // every cluster list-free (A/B variant)
 template <int P>
 __global__ __launch_bounds__(256) void k_pair_clusters_direct(ClusterGeom g, ClusterBuffers b, PairParams pp, double a,
-                                                              double *__restrict__ acc, double *__restrict__ epart) {
+                                                              double *__restrict__ acc, double *__restrict__ epart, int half) {
     const int lane = threadIdx.x & 63;
     const int blk = xcd_remap(blockIdx.x, gridDim.x);
     const int icl = __builtin_amdgcn_readfirstlane(blk * 4 + (threadIdx.x >> 6));
@@ -440,14 +488,15 @@ __global__ __launch_bounds__(256) void k_pair_clusters_direct(ClusterGeom g, Clu
         if (lane == 0) epart[icl] = 0.0;
         return;
     }
-    direct_one_cluster<P>(g, b, pp, a, acc, epart, icl, lane);
+    direct_one_cluster<P>(g, b, pp, a, acc, epart, icl, lane, half != 0);
 }
 
 // only the clusters whose list overflowed (n0 < 0): a small fixed grid scans the list lengths, 64 per wave step,
 // so that the usual case (none) costs a few microseconds
 template <int P>
 __global__ __launch_bounds__(256) void k_pair_clusters_overflow(ClusterGeom g, ClusterBuffers b, PairParams pp, double a,
-                                                                double *__restrict__ acc, double *__restrict__ epart) {
+                                                                double *__restrict__ acc, double *__restrict__ epart,
+                                                                int half) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const int ncl = b.clstart[g.ncols];
@@ -456,39 +505,37 @@ __global__ __launch_bounds__(256) void k_pair_clusters_overflow(ClusterGeom g, C
         while (m) {
             const int l = __ffsll((long long)m) - 1;
             m &= m - 1;
-            direct_one_cluster<P>(g, b, pp, a, acc, epart, base + l, lane);
+            direct_one_cluster<P>(g, b, pp, a, acc, epart, base + l, lane, half != 0);
         }
     }
 }
 
 void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double *acc,
-                          double *epart, int variant, hipEvent_t *ev) {
+                          double *epart, int variant, int n_total, hipEvent_t *ev) {
     const double a = sqrt(pp.a2);
     const int nblk = (g.max_clusters + 3) / 4;
+    const int half = pp.n_owned >= n_total ? 1 : 0; // every particle owned: pair energies are taken from one side
     if (variant == 1) {
-        if (pp.p == 4) hipLaunchKernelGGL((k_pair_clusters_direct<4>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart);
-        else hipLaunchKernelGGL((k_pair_clusters_direct<6>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart);
+        if (pp.p == 4) hipLaunchKernelGGL((k_pair_clusters_direct<4>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart, half);
+        else hipLaunchKernelGGL((k_pair_clusters_direct<6>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart, half);
         return;
     }
     hipLaunchKernelGGL(k_cl_list, dim3(nblk), dim3(256), 0, st, g, b, a, pp.a2, pp.n_owned);
-#define LAUNCH_PC(P, SKIP, U)                                                                                  \
+#define LAUNCH_PC(P, HALF, U)                                                                                  \
     do {                                                                                                       \
         if (ev) hipEventRecord(ev[0], st);                                                                     \
-        hipLaunchKernelGGL((k_pair_clusters<P, SKIP, U>), dim3(nblk), dim3(256), 0, st, g, b, pp, acc, epart); \
+        hipLaunchKernelGGL((k_pair_clusters<P, HALF, U>), dim3(nblk), dim3(256), 0, st, g, b, pp, acc, epart); \
         if (ev) hipEventRecord(ev[1], st);                                                                     \
     } while (0)
+    const bool h = half && variant != 2; // variant 2: every pair counted half from both sides (A/B)
     if (pp.p == 4) {
-        if (variant == 2) LAUNCH_PC(4, true, 4);
-        else if (variant == 3) LAUNCH_PC(4, false, 2);
-        else if (variant == 4) LAUNCH_PC(4, false, 8);
+        if (h) LAUNCH_PC(4, true, 4);
         else LAUNCH_PC(4, false, 4);
-        hipLaunchKernelGGL((k_pair_clusters_overflow<4>), dim3(std::min(nblk, 256)), dim3(256), 0, st, g, b, pp, a, acc, epart);
+        hipLaunchKernelGGL((k_pair_clusters_overflow<4>), dim3(std::min(nblk, 256)), dim3(256), 0, st, g, b, pp, a, acc, epart, h ? 1 : 0);
     } else {
-        if (variant == 2) LAUNCH_PC(6, true, 4);
-        else if (variant == 3) LAUNCH_PC(6, false, 2);
-        else if (variant == 4) LAUNCH_PC(6, false, 8);
+        if (h) LAUNCH_PC(6, true, 4);
         else LAUNCH_PC(6, false, 4);
-        hipLaunchKernelGGL((k_pair_clusters_overflow<6>), dim3(std::min(nblk, 256)), dim3(256), 0, st, g, b, pp, a, acc, epart);
+        hipLaunchKernelGGL((k_pair_clusters_overflow<6>), dim3(std::min(nblk, 256)), dim3(256), 0, st, g, b, pp, a, acc, epart, h ? 1 : 0);
     }
 #undef LAUNCH_PC
 }

@@ -249,7 +249,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         }
         cg.nbins = cg.ncols * cg.nzf;
         cg.max_clusters = (N + CL_G - 1) / CL_G + cg.ncols;
-        cg.list_stride = 256;
+        cg.list_stride = 384; // halves for the later / earlier neighbour clusters, the tail of the second half for shifted ones
         double amax = 0;
         for (int k = 0; k < 3; k++) { cg.A[k] = d.A[k]; cg.invA[k] = 1.0 / d.A[k]; amax = std::max(amax, d.A[k]); }
         cg.pitch[0] = d.A[0] / cg.ncx; cg.pitch[1] = d.A[1] / cg.ncy;
@@ -278,7 +278,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         DA(cb.colncl, cg.ncols + 1); DA(cb.clstart, cg.ncols + 1);
         DA(cb.order, nslots); DA(cb.ps, nslots);
         DA(cb.blo, cg.max_clusters); DA(cb.bhi, cg.max_clusters); DA(cb.fbox, 2 * (size_t)cg.max_clusters);
-        DA(cb.list, (size_t)cg.max_clusters * cg.list_stride); DA(cb.n0, cg.max_clusters); DA(cb.n1, cg.max_clusters);
+        DA(cb.list, (size_t)cg.max_clusters * cg.list_stride); DA(cb.n0, cg.max_clusters); DA(cb.n1, cg.max_clusters); DA(cb.n2, cg.max_clusters);
     }
     h->gq.assign(L, nullptr); h->ge.assign(L, nullptr); h->dK.assign(L, nullptr); h->dKt.assign(L, nullptr);
     for (int l = 0; l < L; l++) {
@@ -341,7 +341,7 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     {
         ClusterBuffers &cb = h->clb;
         hipFree(cb.count); hipFree(cb.start); hipFree(cb.colncl); hipFree(cb.clstart); hipFree(cb.order);
-        hipFree(cb.ps); hipFree(cb.blo); hipFree(cb.bhi); hipFree(cb.fbox); hipFree(cb.list); hipFree(cb.n0); hipFree(cb.n1);
+        hipFree(cb.ps); hipFree(cb.blo); hipFree(cb.bhi); hipFree(cb.fbox); hipFree(cb.list); hipFree(cb.n0); hipFree(cb.n1); hipFree(cb.n2);
     }
     for (auto p : h->gq) hipFree(p);
     for (auto p : h->ge) hipFree(p);
@@ -464,7 +464,7 @@ extern "C" int msm_amd_stage_pairs(msm_amd_handle *h, double *d_acc) {
         if (!h->clusters_sorted)
             launch_cluster_sort(h->stream, h->cur_r, h->cur_q, h->N, h->clg, h->clb, h->bin_of, h->arrival, h->slot_idx, h->scan_tmp);
         h->clusters_sorted = true;
-        launch_pair_clusters(h->stream, h->clg, h->clb, h->pp, d_acc, h->epart, h->opt_pair_variant - 5,
+        launch_pair_clusters(h->stream, h->clg, h->clb, h->pp, d_acc, h->epart, h->opt_pair_variant - 5, h->N,
                              h->profiling ? h->ev_pk : nullptr);
         h->pk_recorded = h->profiling && h->opt_pair_variant != 6;
         h->nepart = h->clg.max_clusters;

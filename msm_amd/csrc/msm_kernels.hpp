@@ -91,7 +91,8 @@ struct ClusterBuffers {
     double4 *ps;                // (x, y, z, q) per slot, absolute coordinates in [0, A)
     double4 *blo, *bhi;         // cluster bounding boxes
     float4 *fbox;               // the same rounded outwards to single precision: [2k] = low corner, [2k+1] = high corner
-    int *list, *n0, *n1;        // neighbour-cluster lists: n0 unshifted entries from the front, n1 shifted from the back
+    int *list, *n0, *n1, *n2;   // neighbour-cluster lists: n0 entries (self + later clusters) from the front, n2 (earlier
+                                // clusters) from the middle, n1 (through a periodic image) from the back; n0 < 0: overflow
 };
 void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, int N, const ClusterGeom &g,
                          const ClusterBuffers &b, int *bin_of, int *arrival, int *slot_idx, int *scan_tmp);
@@ -99,7 +100,7 @@ void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, i
 // evaluates its candidates directly.  Clusters whose list overflowed list_stride are evaluated by the direct kernel.
 // ev (optional): two events recorded immediately before and after the list-walking kernel
 void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double *acc,
-                          double *epart, int variant, hipEvent_t *ev);
+                          double *epart, int variant, int n_total, hipEvent_t *ev);
 
 // ---- short range ----
 void launch_pair_cells(hipStream_t st, const double4 *ps, const int *cstart, const int *order, int ncell,
