@@ -214,6 +214,11 @@ enum { MSM_AMD_U_SHORT_REAL = 0, MSM_AMD_U_SHORT_SELF, MSM_AMD_U_SHORT_CSR, MSM_
 int msm_amd_eval(msm_amd_handle *h, const double *d_r, const double *d_q, double *d_acc, double *energies);
 /* Same through host buffers (H2D 32 B/particle + D2H 24 B/particle included). */
 int msm_amd_eval_host(msm_amd_handle *h, const double *r, const double *q, double *acc, double *energies);
+/* msm_amd_eval without the host synchronisation: the evaluation and a copy of its MSM_AMD_U_COUNT energies into
+ * host_energies (page-locked host memory, e.g. hipHostMalloc; one slot per evaluation in flight) are queued on the
+ * handle's stream and the call returns.  The caller synchronises the stream before reading acc or the energies.
+ * Lets consecutive evaluations queue back to back (a time-stepping loop that reads energies every few steps). */
+int msm_amd_eval_enqueue(msm_amd_handle *h, const double *d_r, const double *d_q, double *d_acc, double *host_energies);
 
 /* ---- stage entry points (device pointers unless noted) ---- */
 /* bin particles; must precede pairs/anterpolate/interpolate of the same positions */

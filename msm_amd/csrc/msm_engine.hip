@@ -788,6 +788,15 @@ extern "C" int msm_amd_eval(msm_amd_handle *h, const double *d_r, const double *
     return MSM_AMD_OK;
 }
 
+extern "C" int msm_amd_eval_enqueue(msm_amd_handle *h, const double *d_r, const double *d_q, double *d_acc,
+                                    double *host_energies) {
+    int rc = msm_amd_eval(h, d_r, d_q, d_acc, nullptr);
+    if (rc) return rc;
+    if (host_energies)
+        HIPCHK(hipMemcpyAsync(host_energies, h->d_energies, MSM_AMD_U_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return MSM_AMD_OK;
+}
+
 extern "C" int msm_amd_last_timings(msm_amd_handle *h, double ms[10]) {
     if (!h || !ms) return MSM_AMD_EINVAL;
     for (int i = 0; i < T_COUNT; i++) ms[i] = h->last_ms[i];

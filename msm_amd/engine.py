@@ -126,6 +126,13 @@ class Engine:
                                   en.ctypes.data_as(_dp) if want_energies else None), "msm_amd_eval")
         return en, acc
 
+    def eval_enqueue(self, r, q, acc, energies_pinned=None):
+        """Queue one evaluation without synchronising.  energies_pinned: a pinned CPU float64 tensor of 7 entries
+        that receives the energies once the stream has been synchronised (None: no copy)."""
+        check(load().msm_amd_eval_enqueue(self._h, r.data_ptr(), q.data_ptr(), acc.data_ptr(),
+                                          energies_pinned.data_ptr() if energies_pinned is not None else None),
+              "msm_amd_eval_enqueue")
+
     def eval_host(self, r, q):
         r = np.ascontiguousarray(r, dtype=np.float64)
         q = np.ascontiguousarray(q, dtype=np.float64)

@@ -240,6 +240,23 @@ def test_wide_stencils(msm, torch, abar, p):
     sp.close()
 
 
+def test_eval_enqueue(msm, torch):
+    """The non-synchronising entry point: several evaluations queued back to back, energies in pinned slots."""
+    N, A = 30000, (1.0, 1.0, 1.0)
+    r, q = O.neutral_system(N, A, seed=3)
+    eng = msm.Engine(msm.plan_auto(N, A, 4, 10, 4.0, 2))
+    rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
+    en, acc = eng.eval(rd, qd)
+    ring = torch.zeros((3, 7), dtype=torch.float64).pin_memory()
+    accs = [torch.zeros_like(acc) for _ in range(3)]
+    for k in range(3):
+        eng.eval_enqueue(rd, qd, accs[k], ring[k])
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert np.array_equal(ring[k].numpy(), en) and torch.equal(accs[k], acc)
+    eng.close()
+
+
 def test_conventions(msm, torch):
     """ACC_LITERAL = msmLibrary.c:168-176 / msmPeriodic.c:1158 weighting, ACC_FORCE = -q_i * gradient."""
     N, A = 2500, (1.0, 1.0, 1.0)
