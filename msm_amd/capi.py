@@ -150,6 +150,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise MsmAmdError("msm_amd/libmsm_amd.so is not built: run `make -C msm_amd/csrc` "
                           "(or __graft_entry__.build()); there is no fallback implementation")
+    # A process must hold ONE HIP runtime.  PyTorch-ROCm ships its own libamdhip64 under the same soname as the
+    # system one this library links against; whichever is loaded first serves both.  The Engine uses torch for
+    # device memory, so torch's copy has to win: import it before the library pulls in the system runtime
+    # (loading this library first and torch afterwards leaves torch on a runtime it was not built for, and the
+    # device then shows up as absent).  Plain C callers are not affected: they never load torch.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here means the header and the library disagree
