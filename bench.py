@@ -16,7 +16,7 @@ particles in a periodic unit cube, quintic B-spline (p = 6) unless --order 4, ab
 levels 96 -> 48 -> 24 -> 12 plus the Fourier top level.  N > 1 keeps the total work fixed (strong scaling):
 the same million particles are split into z slabs.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_pair_clusters, the short-range pair
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_pair_clusters_filtered, the short-range pair
 sum): algorithmic flops (ordered in-cutoff pairs x 34 flop at p=4 / 42 at p=6) over that kernel's mean
 duration, measured with a pair of HIP events recorded around it on the stream it runs on.  `traffic` is the
 HBM-side byte count of one launch from rocprofv3 PMC passes (profiles/r01_pair_traffic.json; null if that
@@ -162,7 +162,7 @@ def main():
                                    % (N, p, "x".join(str(m) for m in desc.M), desc.L, desc.kmax),
                        "particles": N, "order": p, "levels": desc.L, "grid": list(desc.M),
                        "parallelism": "single GPU" if world == 1 else "z-slabs x%d, level-0 charge all-gather" % world},
-            "roofline": {"kernel": "k_pair_clusters (short-range pair sum)", "bound": "mfma", "achieved": achieved,
+            "roofline": {"kernel": "k_pair_clusters_filtered (short-range pair sum)", "bound": "mfma", "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                          "traffic": traffic, "kernel_ms": pair_s * 1e3,
                          "note": "FP64 vector FMA bound (the FP64 MFMA peak is the same 78.6 TF); algorithmic flops = "

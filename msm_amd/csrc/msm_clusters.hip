@@ -8,6 +8,7 @@
 // arithmetic, the j particles come straight from L1/L2 (256 contiguous bytes per cluster pair) and each lane
 // keeps a private partial sum that is reduced over j once at the end.  The summation order is fixed by the
 // sort, so results are the same on every run.  Same mathematics as msmLibrary.c:125-182.
+#include <type_traits>
 #include "msm_kernels.hpp"
 #include "msm_device.hpp"
 
@@ -438,6 +439,112 @@ __global__ __launch_bounds__(256) void k_pair_clusters(ClusterGeom g, ClusterBuf
     cl_finish(I, pp, jj, icl, 2.0 * u1 + uh, fx, fy, fz, acc, epart, lane);
 }
 
+// The list walked at particle granularity.  A listed cluster j has, on average, only a third of its particles
+// within the cutoff of some particle of i, so the wave first tests the 64 particles of 8 listed clusters against
+// the bounding box of i (one particle per lane), compacts the survivors into a ring in LDS, and runs the pair
+// arithmetic on groups of 8 survivors (lane = (ii, jj), jj picks the survivor): about 40 % fewer pair slots for
+// one cheap test per listed particle.  The box test uses the same floating-point expression as the pair distance
+// with |component| no larger, so it can never drop a pair the arithmetic would have kept.  The ring is private
+// to the wave; survivors keep list order, so the sum order is fixed.  Energy bookkeeping as in k_pair_clusters.
+#define CLQ_CAP 128 // ring entries per wave: fewer than 64 pending + 64 new
+template <int P, bool HALF>
+__global__ __launch_bounds__(256) void k_pair_clusters_filtered(ClusterGeom g, ClusterBuffers b, PairParams pp,
+                                                                double *__restrict__ acc, double *__restrict__ epart) {
+    __shared__ double4 ring[4][CLQ_CAP];
+    const int lane = threadIdx.x & 63, ii = lane >> 3, jj = lane & 7;
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int icl = __builtin_amdgcn_readfirstlane(blk * 4 + (threadIdx.x >> 6));
+    if (icl >= g.max_clusters) return;
+    const int ncl = b.clstart[g.ncols];
+    if (icl >= ncl) {
+        if (lane == 0) epart[icl] = 0.0;
+        return;
+    }
+    const int nu = b.n0[icl], ns = b.n1[icl], nd = b.n2[icl];
+    if (nu < 0) return; // list overflow: left to the list-free kernel
+    const LaneI I = load_lane_i(g, b, pp, icl, ii);
+    if (!__ballot(I.owned)) {
+        if (lane == 0) epart[icl] = 0.0;
+        return;
+    }
+    const int S = g.list_stride, MID = S / 2;
+    const int *__restrict__ L = b.list + (size_t)icl * S;
+    double4 *Q = ring[threadIdx.x >> 6];
+    const double4 il = b.blo[icl], ih = b.bhi[icl];
+    const double4 nowhere = make_double4(g.far, g.far, g.far, 0.0);
+    int head = 0, tail = 0; // wave-uniform, only ever incremented; ring index = value mod CLQ_CAP
+    double u1 = 0, uh = 0, fx = 0, fy = 0, fz = 0;
+    cl_slot<P, true>(I.x, I.y, I.z, b.ps[(size_t)CL_G * icl + jj], pp, ii != jj, uh, fx, fy, fz);
+
+    // the 64 particles of 8 list entries, one per lane: survivors of the box test are appended to the ring
+    auto filter = [&](int ent, double4 p, bool valid, bool shifted) {
+        if (shifted) {
+            double sx, sy, sz;
+            shift_of_code(g, (int)((unsigned)ent >> CL_CODE_SHIFT), sx, sy, sz);
+            p.x += sx; p.y += sy; p.z += sz;
+        }
+        const double dx = fmax(fmax(il.x - p.x, p.x - ih.x), 0.0);
+        const double dy = fmax(fmax(il.y - p.y, p.y - ih.y), 0.0);
+        const double dz = fmax(fmax(il.z - p.z, p.z - ih.z), 0.0);
+        const bool keep = valid && fma(dx, dx, fma(dy, dy, dz * dz)) < pp.a2;
+        const unsigned long long m = __ballot(keep);
+        const int pos = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (keep) Q[pos & (CLQ_CAP - 1)] = p;
+        tail += __popcll(m);
+        __builtin_amdgcn_wave_barrier();
+    };
+    // pair arithmetic on the complete groups of 8 in the ring (and, with `final`, on the incomplete last one)
+    auto drain = [&](auto force_only, double &ua, bool final) {
+        constexpr bool FO = decltype(force_only)::value;
+        while (tail - head >= 4 * CL_G) {
+            double4 qv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) qv[k] = Q[(head + CL_G * k + jj) & (CLQ_CAP - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (FO) cl_slot_force<P>(I.x, I.y, I.z, qv[k], pp, fx, fy, fz);
+                else cl_slot<P, false>(I.x, I.y, I.z, qv[k], pp, true, ua, fx, fy, fz);
+            }
+            head += 4 * CL_G;
+        }
+        while (tail - head >= CL_G || (final && tail > head)) {
+            const double4 q = jj < tail - head ? Q[(head + jj) & (CLQ_CAP - 1)] : nowhere;
+            if (FO) cl_slot_force<P>(I.x, I.y, I.z, q, pp, fx, fy, fz);
+            else cl_slot<P, false>(I.x, I.y, I.z, q, pp, true, ua, fx, fy, fz);
+            head = min(head + CL_G, tail);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    using Yes = std::true_type;
+    using No = std::false_type;
+
+    // one part of the list: n entries at base[0], base[dir], ...  Entries are fetched 64 at a time (one per lane)
+    // and handed out 8 per step; the particles of the next step are requested before the current ones are tested.
+    const int sub = lane >> 3;
+    auto walk = [&](const int *__restrict__ base, int dir, int n, bool shifted, auto force_only, double &ua) {
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int mine = c0 + lane < n ? base[dir * (c0 + lane)] : 0;
+            const int steps = (min(64, n - c0) + CL_G - 1) / CL_G;
+            int ent = __shfl(mine, sub);
+            double4 p = b.ps[(size_t)CL_G * (ent & CL_JMASK) + jj];
+            for (int k = 0; k < steps; k++) {
+                const int ent_next = __shfl(mine, (CL_G * (k + 1) + sub) & 63);
+                const double4 p_next = b.ps[(size_t)CL_G * (ent_next & CL_JMASK) + jj];
+                filter(ent, p, c0 + CL_G * k + sub < n, shifted);
+                if (tail - head >= 64) drain(force_only, ua, false);
+                ent = ent_next;
+                p = p_next;
+            }
+        }
+        drain(force_only, ua, true);
+    };
+    walk(L + 1, 1, nu - 1, false, No{}, HALF ? u1 : uh);
+    if (HALF) walk(L + MID, 1, nd, false, Yes{}, uh);
+    else walk(L + MID, 1, nd, false, No{}, uh);
+    walk(L + S - 1, -1, ns, true, No{}, uh);
+    cl_finish(I, pp, jj, icl, 2.0 * u1 + uh, fx, fy, fz, acc, epart, lane);
+}
+
 // The same sum for one cluster without a list: the wave enumerates its candidates and evaluates each surviving
 // cluster pair on the spot.
 template <int P>
@@ -528,16 +635,29 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
         if (ev) hipEventRecord(ev[1], st);                                                                     \
     } while (0)
     const bool h = half && variant != 2; // variant 2: every pair counted half from both sides (A/B)
-    if (pp.p == 4) {
+#define LAUNCH_PF(P, HALF)                                                                                          \
+    do {                                                                                                            \
+        if (ev) hipEventRecord(ev[0], st);                                                                          \
+        hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF>), dim3(nblk), dim3(256), 0, st, g, b, pp, acc, epart); \
+        if (ev) hipEventRecord(ev[1], st);                                                                          \
+    } while (0)
+    if (variant == 3) { // lists walked at particle granularity
+        if (pp.p == 4) { if (h) LAUNCH_PF(4, true); else LAUNCH_PF(4, false); }
+        else { if (h) LAUNCH_PF(6, true); else LAUNCH_PF(6, false); }
+    } else if (pp.p == 4) {
         if (h) LAUNCH_PC(4, true, 4);
         else LAUNCH_PC(4, false, 4);
-        hipLaunchKernelGGL((k_pair_clusters_overflow<4>), dim3(std::min(nblk, 256)), dim3(256), 0, st, g, b, pp, a, acc, epart, h ? 1 : 0);
     } else {
         if (h) LAUNCH_PC(6, true, 4);
         else LAUNCH_PC(6, false, 4);
+    }
+    if (pp.p == 4) {
+        hipLaunchKernelGGL((k_pair_clusters_overflow<4>), dim3(std::min(nblk, 256)), dim3(256), 0, st, g, b, pp, a, acc, epart, h ? 1 : 0);
+    } else {
         hipLaunchKernelGGL((k_pair_clusters_overflow<6>), dim3(std::min(nblk, 256)), dim3(256), 0, st, g, b, pp, a, acc, epart, h ? 1 : 0);
     }
 #undef LAUNCH_PC
+#undef LAUNCH_PF
 }
 
 } // namespace msm

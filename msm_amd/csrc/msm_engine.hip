@@ -60,7 +60,7 @@ struct msm_amd_handle {
     double pair_kernel_ms = -1.0;
     bool ev_made = false;
     double last_ms[T_COUNT];
-    int opt_pair_variant = 5, opt_conv_tiled = 2, opt_conv_small = 1; // conv_tiled: 0 off, 1 per level, 2 levels share a launch
+    int opt_pair_variant = 8, opt_conv_tiled = 2, opt_conv_small = 1; // conv_tiled: 0 off, 1 per level, 2 levels share a launch
     // cluster-pair path of the short-range sum
     ClusterGeom clg;
     ClusterBuffers clb = {};
@@ -459,7 +459,7 @@ extern "C" int msm_amd_stage_pairs(msm_amd_handle *h, double *d_acc) {
         launch_pair_allimages(h->stream, h->cur_r, h->cur_q, h->N, h->pp, d_acc, h->epart, &n);
         h->nepart = n;
     } else if (h->opt_pair_variant >= 5 && h->pp.convention != MSM_AMD_ACC_LITERAL) {
-        // cluster pairs (5: neighbour lists, 6: list-free); the unweighted sums of the literal convention exist
+        // cluster pairs (8: lists walked per particle, 5: per cluster, 6: list-free, 7: no one-sided energies); the unweighted sums of the literal convention exist
         // only in the cell kernels
         if (!h->clusters_sorted)
             launch_cluster_sort(h->stream, h->cur_r, h->cur_q, h->N, h->clg, h->clb, h->bin_of, h->arrival, h->slot_idx, h->scan_tmp);

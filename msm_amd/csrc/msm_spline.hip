@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_anterp_tiles(TileSrc S, SplineParams sp
 // (tile, index inside the tile's node block) pairs that hold contributions to node x of one axis
 template <int P>
 __device__ __forceinline__ int axis_sources(int x, int M, int *ti, int *li) {
-    int n = 0, prev = -1 << 30;
+    int n = 0, prev = -(1 << 30);
 #pragma unroll
     for (int cc = x - P / 2; cc <= x + P / 2 - 1; cc++) { // unwrapped cells whose particles reach node x
         const int k = cc < 0 ? -1 : (cc >= M ? 1 : 0);
