@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmsm_amd.so")
+# MSM_AMD_LIB: another build of the same library (A/B timing of compile-time choices)
+LIB_PATH = os.environ.get("MSM_AMD_LIB") or os.path.join(HERE, "libmsm_amd.so")
 
 LMAX = 10
 U_NAMES = ("ushort_real", "ushort_self", "ushort_csr", "ulong_real", "ulong_four", "ulong_self", "utotal")

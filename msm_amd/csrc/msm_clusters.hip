@@ -80,6 +80,8 @@ __global__ void k_cl_finalize(const double *__restrict__ r, const double *__rest
 __global__ void k_cl_bbox(ClusterGeom g, ClusterBuffers b) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int ncl = b.clstart[g.ncols];
+    // one cluster of inert slots behind the last possible cluster: what a list walk reads past the end of a list
+    if (k < CL_G) b.ps[(size_t)CL_G * g.max_clusters + k] = make_double4(g.far, g.far, g.far, 0.0);
     if (k >= ncl) return;
     int lo = 0, hi = g.ncols; // column with clstart[col] <= k < clstart[col+1]
     while (hi - lo > 1) {
@@ -271,7 +273,11 @@ __global__ __launch_bounds__(256) void k_cl_list(ClusterGeom g, ClusterBuffers b
 // 1/sqrt(x) to double precision: hardware seed (v_rsq_f64, good to better than 2^-20) and one third-order
 // correction, error ~ (5/16) e^3.
 __device__ __forceinline__ double rsqrt_seeded(double x) {
+#ifdef MSM_RSQ_F32
+    const double y0 = (double)__builtin_amdgcn_rsqf((float)x);
+#else
     const double y0 = __builtin_amdgcn_rsq(x);
+#endif
     const double e = fma(-x * y0, y0, 1.0);
     return fma(y0 * e, fma(e, 0.375, 0.5), y0);
 }
@@ -441,16 +447,17 @@ __global__ __launch_bounds__(256) void k_pair_clusters(ClusterGeom g, ClusterBuf
 
 // The list walked at particle granularity.  A listed cluster j has, on average, only a third of its particles
 // within the cutoff of some particle of i, so the wave first tests the 64 particles of 8 listed clusters against
-// the bounding box of i (one particle per lane), compacts the survivors into a ring in LDS, and runs the pair
+// the bounding box of i (one particle per lane), compacts the survivors into a queue in LDS, and runs the pair
 // arithmetic on groups of 8 survivors (lane = (ii, jj), jj picks the survivor): about 40 % fewer pair slots for
 // one cheap test per listed particle.  The box test uses the same floating-point expression as the pair distance
-// with |component| no larger, so it can never drop a pair the arithmetic would have kept.  The ring is private
+// with |component| no larger, so it can never drop a pair the arithmetic would have kept.  The queue is private
 // to the wave; survivors keep list order, so the sum order is fixed.  Energy bookkeeping as in k_pair_clusters.
-#define CLQ_CAP 128 // ring entries per wave: fewer than 64 pending + 64 new
+#define CLQ_CAP 128 // queue entries per wave: fewer than 64 pending + 64 new
+#define CLQ_U 4 // groups per unrolled step of the pair arithmetic (2..4 and 4..6 waves per SIMD all time the same)
 template <int P, bool HALF>
 __global__ __launch_bounds__(256) void k_pair_clusters_filtered(ClusterGeom g, ClusterBuffers b, PairParams pp,
                                                                 double *__restrict__ acc, double *__restrict__ epart) {
-    __shared__ double4 ring[4][CLQ_CAP];
+    __shared__ double4 queue[4][CLQ_CAP];
     const int lane = threadIdx.x & 63, ii = lane >> 3, jj = lane & 7;
     const int blk = xcd_remap(blockIdx.x, gridDim.x);
     const int icl = __builtin_amdgcn_readfirstlane(blk * 4 + (threadIdx.x >> 6));
@@ -469,49 +476,66 @@ __global__ __launch_bounds__(256) void k_pair_clusters_filtered(ClusterGeom g, C
     }
     const int S = g.list_stride, MID = S / 2;
     const int *__restrict__ L = b.list + (size_t)icl * S;
-    double4 *Q = ring[threadIdx.x >> 6];
+    double4 *Q = queue[threadIdx.x >> 6];
     const double4 il = b.blo[icl], ih = b.bhi[icl];
     const double4 nowhere = make_double4(g.far, g.far, g.far, 0.0);
-    int head = 0, tail = 0; // wave-uniform, only ever incremented; ring index = value mod CLQ_CAP
+    int tail = 0; // entries waiting in the queue (wave-uniform)
     double u1 = 0, uh = 0, fx = 0, fy = 0, fz = 0;
     cl_slot<P, true>(I.x, I.y, I.z, b.ps[(size_t)CL_G * icl + jj], pp, ii != jj, uh, fx, fy, fz);
 
-    // the 64 particles of 8 list entries, one per lane: survivors of the box test are appended to the ring
-    auto filter = [&](int ent, double4 p, bool valid, bool shifted) {
+    // the 64 particles of 8 list entries, one per lane: survivors of the box test are appended to the queue
+    // (box as centre and half extent, widened by far more than the rounding of the centre form)
+    const double bcx = 0.5 * (il.x + ih.x), bcy = 0.5 * (il.y + ih.y), bcz = 0.5 * (il.z + ih.z);
+    const double bhx = 0.5 * (ih.x - il.x) + 1e-13 * g.A[0], bhy = 0.5 * (ih.y - il.y) + 1e-13 * g.A[1],
+                 bhz = 0.5 * (ih.z - il.z) + 1e-13 * g.A[2];
+    auto filter = [&](unsigned ent, double4 p, bool shifted) {
         if (shifted) {
             double sx, sy, sz;
-            shift_of_code(g, (int)((unsigned)ent >> CL_CODE_SHIFT), sx, sy, sz);
+            shift_of_code(g, (int)(ent >> CL_CODE_SHIFT), sx, sy, sz);
             p.x += sx; p.y += sy; p.z += sz;
         }
-        const double dx = fmax(fmax(il.x - p.x, p.x - ih.x), 0.0);
-        const double dy = fmax(fmax(il.y - p.y, p.y - ih.y), 0.0);
-        const double dz = fmax(fmax(il.z - p.z, p.z - ih.z), 0.0);
-        const bool keep = valid && fma(dx, dx, fma(dy, dy, dz * dz)) < pp.a2;
+        const double dx = fmax(fabs(p.x - bcx) - bhx, 0.0);
+        const double dy = fmax(fabs(p.y - bcy) - bhy, 0.0);
+        const double dz = fmax(fabs(p.z - bcz) - bhz, 0.0);
+        const bool keep = fma(dx, dx, fma(dy, dy, dz * dz)) < pp.a2;
         const unsigned long long m = __ballot(keep);
         const int pos = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        if (keep) Q[pos & (CLQ_CAP - 1)] = p;
+        if (keep) Q[pos] = p;
         tail += __popcll(m);
         __builtin_amdgcn_wave_barrier();
     };
-    // pair arithmetic on the complete groups of 8 in the ring (and, with `final`, on the incomplete last one)
+    // pair arithmetic on the complete groups of 8 in the queue (and, with `final`, on the incomplete last one)
     auto drain = [&](auto force_only, double &ua, bool final) {
         constexpr bool FO = decltype(force_only)::value;
-        while (tail - head >= 4 * CL_G) {
-            double4 qv[4];
+        const double4 *qr = Q + jj; // group k of the queue, as seen by this lane: qr[8 k]
+        int done = 0;
+        for (; done + CLQ_U * CL_G <= tail; done += CLQ_U * CL_G) {
+            double4 qv[CLQ_U];
 #pragma unroll
-            for (int k = 0; k < 4; k++) qv[k] = Q[(head + CL_G * k + jj) & (CLQ_CAP - 1)];
+            for (int k = 0; k < CLQ_U; k++) qv[k] = qr[done + CL_G * k];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < CLQ_U; k++) {
                 if (FO) cl_slot_force<P>(I.x, I.y, I.z, qv[k], pp, fx, fy, fz);
                 else cl_slot<P, false>(I.x, I.y, I.z, qv[k], pp, true, ua, fx, fy, fz);
             }
-            head += 4 * CL_G;
         }
-        while (tail - head >= CL_G || (final && tail > head)) {
-            const double4 q = jj < tail - head ? Q[(head + jj) & (CLQ_CAP - 1)] : nowhere;
+        for (; done + CL_G <= tail; done += CL_G) {
+            const double4 q = qr[done];
             if (FO) cl_slot_force<P>(I.x, I.y, I.z, q, pp, fx, fy, fz);
             else cl_slot<P, false>(I.x, I.y, I.z, q, pp, true, ua, fx, fy, fz);
-            head = min(head + CL_G, tail);
+        }
+        const int rem = tail - done;
+        if (final) {
+            if (rem > 0) {
+                const double4 q = jj < rem ? qr[done] : nowhere;
+                if (FO) cl_slot_force<P>(I.x, I.y, I.z, q, pp, fx, fy, fz);
+                else cl_slot<P, false>(I.x, I.y, I.z, q, pp, true, ua, fx, fy, fz);
+            }
+            tail = 0;
+        } else {
+            // the incomplete last group moves to the front (done >= 64 > rem: source and destination are disjoint)
+            if (lane < rem) Q[lane] = Q[done + lane];
+            tail = rem;
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -519,21 +543,31 @@ __global__ __launch_bounds__(256) void k_pair_clusters_filtered(ClusterGeom g, C
     using No = std::false_type;
 
     // one part of the list: n entries at base[0], base[dir], ...  Entries are fetched 64 at a time (one per lane)
-    // and handed out 8 per step; the particles of the next step are requested before the current ones are tested.
+    // and handed out 8 per step (past the end of the list: the cluster of inert slots, which fails the box test);
+    // the particles of the next step are requested before the current ones are tested.
     const int sub = lane >> 3;
+    const char *__restrict__ psb = (const char *)b.ps + 32 * jj;
+    auto particle = [&](unsigned ent, bool shifted) { // byte offsets stay below 2^32: checked by the launcher
+        return *(const double4 *)(psb + ((shifted ? ent & (unsigned)CL_JMASK : ent) << 8));
+    };
     auto walk = [&](const int *__restrict__ base, int dir, int n, bool shifted, auto force_only, double &ua) {
+        const unsigned pad = (unsigned)g.max_clusters | (shifted ? (unsigned)CL_NOSHIFT << CL_CODE_SHIFT : 0u);
         for (int c0 = 0; c0 < n; c0 += 64) {
-            const int mine = c0 + lane < n ? base[dir * (c0 + lane)] : 0;
+            const unsigned mine = c0 + lane < n ? (unsigned)base[dir * (c0 + lane)] : pad;
             const int steps = (min(64, n - c0) + CL_G - 1) / CL_G;
-            int ent = __shfl(mine, sub);
-            double4 p = b.ps[(size_t)CL_G * (ent & CL_JMASK) + jj];
-            for (int k = 0; k < steps; k++) {
-                const int ent_next = __shfl(mine, (CL_G * (k + 1) + sub) & 63);
-                const double4 p_next = b.ps[(size_t)CL_G * (ent_next & CL_JMASK) + jj];
-                filter(ent, p, c0 + CL_G * k + sub < n, shifted);
-                if (tail - head >= 64) drain(force_only, ua, false);
-                ent = ent_next;
-                p = p_next;
+            unsigned ea = __shfl(mine, sub);
+            double4 pa = particle(ea, shifted);
+            for (int k = 0; k < steps; k += 2) {
+                const unsigned eb = __shfl(mine, CL_G * (k + 1) + sub); // lane index taken mod 64
+                const double4 pb = particle(eb, shifted);
+                filter(ea, pa, shifted);
+                if (tail >= 64) drain(force_only, ua, false);
+                ea = __shfl(mine, CL_G * (k + 2) + sub);
+                pa = particle(ea, shifted);
+                if (k + 1 < steps) {
+                    filter(eb, pb, shifted);
+                    if (tail >= 64) drain(force_only, ua, false);
+                }
             }
         }
         drain(force_only, ua, true);
@@ -641,7 +675,7 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
         hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF>), dim3(nblk), dim3(256), 0, st, g, b, pp, acc, epart); \
         if (ev) hipEventRecord(ev[1], st);                                                                          \
     } while (0)
-    if (variant == 3) { // lists walked at particle granularity
+    if (variant == 3 && g.max_clusters < (1 << 24)) { // lists walked at particle granularity (32-bit byte offsets)
         if (pp.p == 4) { if (h) LAUNCH_PF(4, true); else LAUNCH_PF(4, false); }
         else { if (h) LAUNCH_PF(6, true); else LAUNCH_PF(6, false); }
     } else if (pp.p == 4) {

@@ -276,7 +276,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         const size_t nslots = (size_t)cg.max_clusters * CL_G;
         DA(cb.count, cg.nbins); DA(cb.start, cg.nbins + 1);
         DA(cb.colncl, cg.ncols + 1); DA(cb.clstart, cg.ncols + 1);
-        DA(cb.order, nslots); DA(cb.ps, nslots);
+        DA(cb.order, nslots); DA(cb.ps, nslots + CL_G); // + one cluster of inert slots behind the last one
         DA(cb.blo, cg.max_clusters); DA(cb.bhi, cg.max_clusters); DA(cb.fbox, 2 * (size_t)cg.max_clusters);
         DA(cb.list, (size_t)cg.max_clusters * cg.list_stride); DA(cb.n0, cg.max_clusters); DA(cb.n1, cg.max_clusters); DA(cb.n2, cg.max_clusters);
     }

@@ -54,6 +54,13 @@ __device__ __forceinline__ void tile_run(const TileSrc &S, const SplineParams &s
 // cell of a coordinate (grid units), kept inside the tile whatever the last bit of the product did
 __device__ __forceinline__ int tile_cell(double u, int c0, int n) { return min(max((int)u, c0), c0 + n - 1); }
 
+// Fire-and-forget addition in LDS (ds_add_f64): nothing comes back, so consecutive particles do not wait for
+// each other's round trip.  The block a wave adds into is private to it and LDS serves a wave's requests in
+// program order, so every node still receives its terms in a fixed order.
+__device__ __forceinline__ void lds_add(double *p, double v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
 template <int P>
 __global__ __launch_bounds__(256) void k_anterp_tiles(TileSrc S, SplineParams sp, TileGeom tl, double *__restrict__ scratch,
                                                       int *__restrict__ tile_used) {
@@ -115,17 +122,14 @@ __global__ __launch_bounds__(256) void k_anterp_tiles(TileSrc S, SplineParams sp
                 const double wxy = piece_eval<P>(cx, fx) * piece_eval<P>(cy, fy);
                 if (P == 4) {
                     const double fz = readlane_d(lfz, k), pq = readlane_d(ptl.w, k);
-                    mine[base] += pq * wxy * piece_eval<P>(cz, fz);
+                    lds_add(mine + base, pq * wxy * piece_eval<P>(cz, fz));
                 } else {
                     double wz[P];
 #pragma unroll
                     for (int cc = 0; cc < P; cc++) wz[cc] = readlane_d(lwz[cc], k);
                     if (active) {
-                        double v[P];
 #pragma unroll
-                        for (int cc = 0; cc < P; cc++) v[cc] = mine[base + cc * R * R];
-#pragma unroll
-                        for (int cc = 0; cc < P; cc++) mine[base + cc * R * R] = fma(wxy, wz[cc], v[cc]);
+                        for (int cc = 0; cc < P; cc++) lds_add(mine + base + cc * R * R, wxy * wz[cc]);
                     }
                 }
             }
