@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--levels", type=int, default=0, help="grid levels (0: the reference's formula, capped)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pair-variant", type=int, default=-1)
+    ap.add_argument("--no-accuracy", action="store_true", help="skip the Ewald reference (error of the MSM result)")
     args = ap.parse_args()
 
     import torch
@@ -100,8 +101,8 @@ def main():
         torch.cuda.synchronize()
 
     ref_eval = None
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        ref_eval = stepper.eval_unperturbed()   # untimed: the same positions the CPU oracle gets
+    if world == 1 and rank == 0 and not (args.no_cpu_baseline and args.no_accuracy):
+        ref_eval = stepper.eval_unperturbed()   # untimed: the same positions the CPU oracle and the Ewald sum get
 
     for _ in range(args.warmup):
         stepper.step()
@@ -137,6 +138,9 @@ def main():
                   "utotal_gpu": float(en_gpu[6]), "utotal_cpu": float(en_cpu[6]),
                   "acc_rel_rms_diff": float(np.sqrt((da ** 2).sum() / (cpu_out["acc"] ** 2).sum())),
                   "tolerance": 1e-12}
+    accuracy = None
+    if rank == 0 and world == 1 and not args.no_accuracy:
+        accuracy = ewald_accuracy(torch, msm_amd, r_all, q_all, A, ref_eval[0], ref_eval[1], dev)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_pair_traffic.json")
     if world == 1 and os.path.exists(tpath):
@@ -173,9 +177,37 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["parity"] = parity
+        if accuracy is not None:
+            out["accuracy"] = accuracy
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def ewald_accuracy(torch, msm_amd, r_all, q_all, A, en_msm, acc_msm, dev):
+    """Error of the MSM evaluation against a converged Ewald sum of the same system, computed on the GPU
+    (msm_amd_ewald_device, all particles; outside the timed region)."""
+    rcut = 0.25 * min(A)
+    alpha = 5.6 / rcut                                   # erfc(alpha rcut) ~ 2e-15
+    kcut = int(math.ceil(5.6 * alpha * max(A) / math.pi))  # exp(-(pi k / alpha)^2) ~ 2e-14 at the edge of the cube
+    r = torch.as_tensor(r_all, device=dev)
+    q = torch.as_tensor(q_all, device=dev)
+    # neighbours in space next to each other in memory: the 64 particles of a wave then share their in-range partners
+    nb = 32
+    cell = [(r[:, d] / A[d] * nb).long().clamp_(0, nb - 1) for d in range(3)]
+    perm = torch.argsort((cell[2] * nb + cell[1]) * nb + cell[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    u5, _, grad_sorted = msm_amd.ewald(r[perm], q[perm], A, alpha, rcut, kcut)
+    torch.cuda.synchronize()
+    secs = time.perf_counter() - t0
+    grad = torch.empty_like(grad_sorted)
+    grad[perm] = grad_sorted
+    d = torch.as_tensor(acc_msm, device=dev) - grad
+    return {"reference": "Ewald sum on the GPU (alpha=%g, rcut=%g, |k_d|<=%d), all %d particles" % (alpha, rcut, kcut, len(q_all)),
+            "force_rms_rel_error": float(torch.sqrt((d ** 2).sum() / (grad ** 2).sum())),
+            "energy_rel_error": float(abs(en_msm[6] - u5[4]) / abs(u5[4])),
+            "utotal_ewald": float(u5[4]), "utotal_msm": float(en_msm[6]), "reference_seconds": secs}
 
 
 class SingleGpu:

@@ -119,6 +119,13 @@ double msmPeriodicRunner(double *r, double *q, double *f, int n, int p, int mu, 
  * computation of msm/nonperiodic.c:12-22 (which forces q = 1). */
 void direct(int N, double *r, double *q, double *ureal, double *freal);
 
+/* Ewald sum of a periodic system on the GPU, host pointers: the total energy, with the three report lines on stderr.
+ * replaces ewaldClassical(), msm/ewaldClassical.h:6, defined at msm/ewaldClassical.c:5-109 (real sum over the
+ * particles as given, no images; reciprocal sum over kx^2+ky^2+kz^2 < cutoffFourier^2).  Returns NaN after
+ * printing the reason if no GPU is visible or a HIP call fails. */
+double ewaldClassical(double *r, double *q, int n, double Lx, double Ly, double Lz, double alpha, double cutoffDirect,
+                      double cutoffFourier);
+
 /* parameter helpers, msm/msmLibrary.h:191-192,238-247 / msm/msmLibrary.c:3,31,46,69,110,283 */
 double mylog2(double x);
 double choosebetaNew(double epsilon, double aL, double hL);
@@ -288,6 +295,20 @@ int msm_amd_hostplan_scalars(msm_amd_hostplan *hp, double out[8]);
 int msm_amd_direct_work_doubles(int N);
 int msm_amd_direct_device(int N, const double *d_r, const double *d_q, int i0, int i1, int acc_convention, double *d_acc,
                           double *d_work, void *stream, double *u);
+
+/* Device-resident Ewald sum: potential d_phi[i1 - i0] and its gradient d_grad[3 (i1 - i0)] (may be NULL) at
+ * particles [i0, i1) of the N in d_r/d_q, cell edges A[3].  mode MSM_AMD_EWALD_FULL: nearest image inside rcut
+ * (rcut <= half the shortest edge), every |k_d| <= ceil(kcut): the converged sum that accuracy figures are
+ * quoted against (energy as msm/ewaldClassical.c:5-109 with the image handling its comments leave out, gradient
+ * as tabulated by msm/ewaldHernquist.c:113-172).  MSM_AMD_EWALD_LITERAL: the sums exactly as ewaldClassical()
+ * takes them.  d_work needs msm_amd_ewald_work_doubles(N, kcut, i1 - i0) doubles; on return d_work[0..4] hold
+ * the shares of particles [i0, i1) in the [real, reciprocal, self, background, total] energy (1/2 q_i phi_i summed),
+ * copied to u5 when u5 != NULL (synchronises the stream). */
+#define MSM_AMD_EWALD_FULL 0
+#define MSM_AMD_EWALD_LITERAL 1
+long long msm_amd_ewald_work_doubles(int N, double kcut, int ni);
+int msm_amd_ewald_device(int N, const double *d_r, const double *d_q, const double A[3], double alpha, double rcut, double kcut,
+                         int mode, int i0, int i1, double *d_phi, double *d_grad, double *d_work, void *stream, double *u5);
 
 const char *msm_amd_last_error(void);
 int msm_amd_device_count(void);

@@ -14,6 +14,7 @@ LMAX = 10
 U_NAMES = ("ushort_real", "ushort_self", "ushort_csr", "ulong_real", "ulong_four", "ulong_self", "utotal")
 U_COUNT = 7
 ACC_GRADIENT, ACC_LITERAL, ACC_FORCE = 0, 1, 2
+EWALD_FULL, EWALD_LITERAL = 0, 1
 MODE_AUTO, MODE_LITERAL, MODE_SCALABLE = 0, 1, 2
 GRID_Q, GRID_E, GRID_EFOUR = 0, 1, 2
 
@@ -119,6 +120,10 @@ SIGNATURES = {
     "msm_amd_op_prolong_add": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "msm_amd_op_convolve": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "direct": (None, [C.c_int, _dp, _dp, _dp, _dp]),
+    "ewaldClassical": (C.c_double, [_dp, _dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "msm_amd_ewald_work_doubles": (C.c_longlong, [C.c_int, C.c_double, C.c_int]),
+    "msm_amd_ewald_device": (C.c_int, [C.c_int, _vp, _vp, _dp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
+                                       _vp, _vp, _vp, _vp, _dp]),
     "msm_amd_direct_work_doubles": (C.c_int, [C.c_int]),
     "msm_amd_direct_device": (C.c_int, [C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _dp]),
     "msm_amd_last_timings": (C.c_int, [_vp, _dp]),

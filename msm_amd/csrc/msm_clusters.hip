@@ -686,9 +686,9 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
         else LAUNCH_PC(6, false, 4);
     }
     if (pp.p == 4) {
-        hipLaunchKernelGGL((k_pair_clusters_overflow<4>), dim3(std::min(nblk, 256)), dim3(256), 0, st, g, b, pp, a, acc, epart, h ? 1 : 0);
+        hipLaunchKernelGGL((k_pair_clusters_overflow<4>), dim3(std::min(nblk, 2048)), dim3(256), 0, st, g, b, pp, a, acc, epart, h ? 1 : 0);
     } else {
-        hipLaunchKernelGGL((k_pair_clusters_overflow<6>), dim3(std::min(nblk, 256)), dim3(256), 0, st, g, b, pp, a, acc, epart, h ? 1 : 0);
+        hipLaunchKernelGGL((k_pair_clusters_overflow<6>), dim3(std::min(nblk, 2048)), dim3(256), 0, st, g, b, pp, a, acc, epart, h ? 1 : 0);
     }
 #undef LAUNCH_PC
 #undef LAUNCH_PF

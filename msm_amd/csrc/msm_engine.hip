@@ -43,6 +43,9 @@ struct msm_amd_handle {
     int *scan_tmp = nullptr;
     // grids
     std::vector<double *> gq, ge, dK, dKt;
+    // stencils wider than the tiled convolution handles in one piece: cut into sub_n^3 cubes of sub_s^3 taps
+    std::vector<double *> dKsub;
+    std::vector<int> sub_s, sub_n;
     double *efour = nullptr, *dKL = nullptr, *tmpA = nullptr, *tmpB = nullptr;
     // reductions
     double *epart = nullptr;
@@ -249,7 +252,18 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         }
         cg.nbins = cg.ncols * cg.nzf;
         cg.max_clusters = (N + CL_G - 1) / CL_G + cg.ncols;
-        cg.list_stride = 384; // halves for the later / earlier neighbour clusters, the tail of the second half for shifted ones
+        {
+            // list length: halves for the later / earlier neighbour clusters, the tail of the second half for shifted
+            // ones.  Expected neighbours of a cluster = clusters in the volume within a of a cube of its size,
+            // times 1.5 for ragged boxes; each half gets 1.3 times that (half of it would do on average).
+            const double vol = d.A[0] * d.A[1] * d.A[2], e = std::cbrt(8.0 * vol / N), a = d.a;
+            const double vexp = e * e * e + 6.0 * e * e * a + 3.0 * M_PI * a * a * e + 4.0 / 3.0 * M_PI * a * a * a;
+            const double est = 1.5 * vexp * N / (8.0 * vol);
+            long half = std::max(192L, ((long)(1.3 * est) + 31) / 32 * 32);
+            const long cap = (1L << 29) / std::max(1, cg.max_clusters) / 2 / 32 * 32; // lists of at most 2 GB
+            half = std::max(192L, std::min(half, cap));
+            cg.list_stride = (int)(2 * half);
+        }
         double amax = 0;
         for (int k = 0; k < 3; k++) { cg.A[k] = d.A[k]; cg.invA[k] = 1.0 / d.A[k]; amax = std::max(amax, d.A[k]); }
         cg.pitch[0] = d.A[0] / cg.ncx; cg.pitch[1] = d.A[1] / cg.ncy;
@@ -281,6 +295,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         DA(cb.list, (size_t)cg.max_clusters * cg.list_stride); DA(cb.n0, cg.max_clusters); DA(cb.n1, cg.max_clusters); DA(cb.n2, cg.max_clusters);
     }
     h->gq.assign(L, nullptr); h->ge.assign(L, nullptr); h->dK.assign(L, nullptr); h->dKt.assign(L, nullptr);
+    h->dKsub.assign(L, nullptr); h->sub_s.assign(L, 0); h->sub_n.assign(L, 0);
     for (int l = 0; l < L; l++) {
         const size_t n = (size_t)h->hp.Ml[l][0] * h->hp.Ml[l][1] * h->hp.Ml[l][2];
         DA(h->gq[l], n); DA(h->ge[l], n);
@@ -296,6 +311,26 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
                 for (int sx = 0; sx < S.size[0]; sx++)
                     t[((size_t)sy * S.size[0] + sx) * S.size[2] + sz] = S.v[((size_t)sz * S.size[1] + sy) * S.size[0] + sx];
         HIPCHK(hipMemcpy(h->dKt[l], t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+        if (!literal && S.size[0] == S.size[1] && S.size[1] == S.size[2] && S.size[0] > 23) {
+            // smallest padded width n * s over the cube sizes the kernel is built for; ties go to fewer cubes
+            const int W = S.size[0];
+            int bs = 0, bn = 0;
+            for (int sz = 9; sz <= 23; sz += 2) {
+                const int n = (W + sz - 1) / sz;
+                if (!bs || n * sz < bn * bs || (n * sz == bn * bs && n < bn)) { bs = sz; bn = n; }
+            }
+            std::vector<double> sub((size_t)bn * bn * bn * bs * bs * bs, 0.0);
+            for (int z = 0; z < W; z++)
+                for (int y = 0; y < W; y++)
+                    for (int x = 0; x < W; x++) {
+                        const size_t cube = ((size_t)(z / bs) * bn + y / bs) * bn + x / bs;
+                        sub[cube * bs * bs * bs + ((size_t)(y % bs) * bs + x % bs) * bs + z % bs] = S.v[((size_t)z * W + y) * W + x];
+                    }
+            DA(h->dKsub[l], sub.size());
+            HIPCHK(hipMemcpy(h->dKsub[l], sub.data(), sub.size() * sizeof(double), hipMemcpyHostToDevice));
+            h->sub_s[l] = bs;
+            h->sub_n[l] = bn;
+        }
     }
     {
         const size_t nL = h->hp.KL.v.size(), n0 = (size_t)d.M[0] * d.M[1] * d.M[2];
@@ -347,6 +382,7 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     for (auto p : h->ge) hipFree(p);
     for (auto p : h->dK) hipFree(p);
     for (auto p : h->dKt) hipFree(p);
+    for (auto p : h->dKsub) hipFree(p);
     hipFree(h->efour); hipFree(h->dKL); hipFree(h->tmpA); hipFree(h->tmpB); hipFree(h->epart); hipFree(h->parts);
     hipFree(h->d_energies);
     if (h->h_energies) hipHostFree(h->h_energies);
@@ -583,11 +619,13 @@ extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
             const LevelStencil &S = h->hp.K[r.l];
             const int *M = h->hp.Ml[r.l];
             if (!(M[0] >= 16 && M[1] >= 8 && M[2] >= 8)) continue; // a short plane range of a large grid is fine
-            if (B.n > 0 && S.size[2] != B.c[0].ks[2]) continue;
+            const int width = h->sub_n[r.l] ? h->sub_s[r.l] : S.size[2]; // taps per axis the kernel is instantiated for
+            if (B.n > 0 && width != B.c[0].ks[2]) continue;
             ConvArgs &c = B.c[B.n];
-            for (int k = 0; k < 3; k++) { c.M[k] = M[k]; c.ks[k] = S.size[k]; c.kf[k] = S.first[k]; }
+            for (int k = 0; k < 3; k++) { c.M[k] = M[k]; c.ks[k] = h->sub_n[r.l] ? width : S.size[k]; c.kf[k] = S.first[k]; }
             c.z0 = r.z0; c.nz = r.nz; c.accumulate = 0;
-            B.q[B.n] = h->gq[r.l]; B.Kt[B.n] = h->dKt[r.l]; B.e[B.n] = h->ge[r.l];
+            c.nsub = h->sub_n[r.l] ? h->sub_n[r.l] : 1;
+            B.q[B.n] = h->gq[r.l]; B.Kt[B.n] = h->sub_n[r.l] ? h->dKsub[r.l] : h->dKt[r.l]; B.e[B.n] = h->ge[r.l];
             B.n++;
             members.push_back(i);
         }

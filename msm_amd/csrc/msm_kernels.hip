@@ -1145,7 +1145,6 @@ __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
     while (lev + 1 < B.n && (int)blockIdx.x >= B.blk0[lev + 1]) lev++;
     const ConvArgs c = B.c[lev];
     const double *__restrict__ q = B.q[lev];
-    const double *__restrict__ Kt = B.Kt[lev];
     double *__restrict__ e = B.e[lev];
     const int ntx = B.ntx[lev], nty = B.nty[lev];
     const int Mx = c.M[0], My = c.M[1], Mz = c.M[2];
@@ -1159,21 +1158,26 @@ __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
     const int bid = blockIdx.x - B.blk0[lev];
     const int bx = bid % ntx, by = (bid / ntx) % nty, bz = bid / (ntx * nty);
     const int X0 = bx * TX, Y0 = by * TY, Z0 = c.z0 + bz * TZ;
-    const int ox = X0 - (c.kf[0] + SZ - 1), oy = Y0 - (c.kf[1] + SZ - 1), oz = Z0 - (c.kf[2] + SZ - 1);
     constexpr int NT = TX * TY * (TZ / R);
     const int tx = threadIdx.x % TX, ty = (threadIdx.x / TX) % TY, tg = threadIdx.x / (TX * TY);
     constexpr int W = R + SZ - 1;
     constexpr int plane = LX * LY;
     const int half = threadIdx.x >> 5, hl = threadIdx.x & 31;
-    const int gx0 = modp(ox + hl, Mx), gx1 = modp(ox + hl + 32, Mx);
     double acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.0;
+    // a stencil wider than the kernel's SZ comes as nsub^3 cubes of SZ^3 taps, applied one after the other
+    const int ncube = c.nsub * c.nsub * c.nsub;
+    for (int cube = 0; cube < ncube; cube++) {
+    const int ca = cube % c.nsub, cb = (cube / c.nsub) % c.nsub, cc = cube / (c.nsub * c.nsub);
+    const int ox = X0 - (c.kf[0] + ca * SZ + SZ - 1), oy = Y0 - (c.kf[1] + cb * SZ + SZ - 1), oz = Z0 - (c.kf[2] + cc * SZ + SZ - 1);
+    const double *__restrict__ Kt = B.Kt[lev] + (size_t)cube * (SZ * SZ * SZ);
+    const int gx0 = modp(ox + hl, Mx), gx1 = modp(ox + hl + 32, Mx);
     for (int c0 = 0; c0 < SZ; c0 += CHR) {
         const int nch = min(CHR, SZ - c0); // this pass applies the taps sy in [c0, c0 + nch)
         const int ys = SZ - c0 - nch;      // first y row (of the full halo) they touch
         const int rows = TY + nch - 1;
-        if (c0 > 0) __syncthreads();
+        if (c0 > 0 || cube > 0) __syncthreads();
         {
             // staging: half a wave per (z, y) row of the tile, lanes along x; the periodic wrap is done once per
             // row (no integer division per element), and the loads of 8 rows are issued before the first store
@@ -1250,6 +1254,7 @@ __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
             }
         }
     }
+    }
     const int mx = X0 + tx, my = Y0 + ty;
     if (mx < Mx && my < My) {
 #pragma unroll
@@ -1269,7 +1274,7 @@ static bool conv_multi_launch(hipStream_t st, ConvBatch &B) {
     int nblk = 0;
     for (int l = 0; l < B.n; l++) {
         const ConvArgs &c = B.c[l];
-        if (c.ks[0] != SZ || c.ks[1] != SZ || c.ks[2] != SZ) return false;
+        if (c.ks[0] != SZ || c.ks[1] != SZ || c.ks[2] != SZ || c.nsub < 1) return false;
         B.ntx[l] = (c.M[0] + TX - 1) / TX;
         B.nty[l] = (c.M[1] + TY - 1) / TY;
         B.blk0[l] = nblk;

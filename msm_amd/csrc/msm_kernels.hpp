@@ -139,6 +139,9 @@ void launch_prolong_axis(hipStream_t st, const double *in, double *out, const in
 struct ConvArgs {
     int M[3], ks[3], kf[3];
     int z0, nz, accumulate;
+    // k_conv_multi only: the stencil is nsub^3 cubes of ks^3 taps, cube (a, b, c) starting at offset kf + ks (a, b, c),
+    // stored one after the other (a fastest), each transposed [sy][sx][sz]
+    int nsub = 1;
 };
 // up to 8 convolutions (levels, or plane ranges of a level) that share one launch
 struct ConvBatch {

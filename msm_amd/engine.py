@@ -266,6 +266,44 @@ def direct(r, q):
     return u.value, f
 
 
+def ewaldClassical(r, q, A, alpha, cutoffDirect, cutoffFourier):
+    """ewaldClassical() of msm/ewaldClassical.h:6 through the C ABI (host arrays): the total energy."""
+    lib = load()
+    r = np.ascontiguousarray(r, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    return lib.ewaldClassical(r.ctypes.data_as(_dp), q.ctypes.data_as(_dp), q.shape[0], float(A[0]), float(A[1]), float(A[2]),
+                              float(alpha), float(cutoffDirect), float(cutoffFourier))
+
+
+def ewald(r, q, A, alpha, rcut, kcut, i0=0, i1=None, literal=False, want_grad=True):
+    """Ewald potential and gradient at particles [i0, i1) on the GPU (msm_amd_ewald_device).
+
+    r (N,3), q (N,): float64 CUDA tensors or host arrays.  Returns (energies, phi, grad): energies is the array
+    [real, reciprocal, self, background, total] of the slice's share 1/2 sum q_i phi_i, phi and grad are CUDA tensors."""
+    import torch
+    lib = load()
+    dev = r.device if isinstance(r, torch.Tensor) and r.is_cuda else torch.device("cuda:0")
+    rd = torch.as_tensor(r, dtype=torch.float64, device=dev).contiguous()
+    qd = torch.as_tensor(q, dtype=torch.float64, device=dev).contiguous()
+    n = qd.shape[0]
+    i1 = n if i1 is None else i1
+    nw = lib.msm_amd_ewald_work_doubles(n, float(kcut), i1 - i0)
+    if nw <= 0:
+        raise capi.MsmAmdError("msm_amd_ewald_work_doubles: bad argument")
+    work = torch.empty(nw, dtype=torch.float64, device=dev)
+    phi = torch.empty(i1 - i0, dtype=torch.float64, device=dev)
+    grad = torch.empty((i1 - i0, 3), dtype=torch.float64, device=dev) if want_grad else None
+    Aa = (C.c_double * 3)(*[float(a) for a in A])
+    u5 = np.zeros(5)
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream().cuda_stream
+        check(lib.msm_amd_ewald_device(n, rd.data_ptr(), qd.data_ptr(), Aa, float(alpha), float(rcut), float(kcut),
+                                       capi.EWALD_LITERAL if literal else capi.EWALD_FULL, i0, i1, phi.data_ptr(),
+                                       grad.data_ptr() if want_grad else None, work.data_ptr(), st, u5.ctypes.data_as(_dp)),
+              "ewald")
+    return u5, phi, grad
+
+
 def msmperiodic(r, q, p, abar, mu, A, mode=None, quiet=True):
     """msmperiodic() of msm/msmLibrary.h:188 through the C ABI.
 

@@ -240,6 +240,31 @@ def test_wide_stencils(msm, torch, abar, p):
     sp.close()
 
 
+@pytest.mark.parametrize("a_over_h,p,width", [(6.3, 4, 25), (7.6, 6, 31), (8.8, 4, 35)])
+def test_very_wide_stencils(msm, torch, a_over_h, p, width):
+    """Stencils beyond 23 taps per axis (a grid of half the usual spacing, or a long cutoff) are cut into cubes that
+    the multi-level convolution kernel applies one after the other: grids and totals against the oracle."""
+    N, A, M, L = 12000, (1.0, 1.0, 1.0), (48, 48, 48), 2
+    r, q = O.neutral_system(N, A, seed=37)
+    lib = msm.load()
+    a = a_over_h / M[0]
+    hL = (2.0 ** (L - 1)) * A[0] / M[0]
+    beta = lib.choosebetaNew(1e-12, (2.0 ** L) * a, hL)
+    kmax = int(np.ceil(lib.choosekmax(1e-12, beta, hL)))
+    desc = msm.plan_explicit(N, A, M, p, 10, L, a, beta, kmax)
+    eng = msm.Engine(desc)
+    assert eng.stencil(0)[0].shape[0] == width
+    sp = spec_for(desc)
+    ref = sp.eval(r, q)
+    en, acc = eng.eval(r, q)
+    for l in range(desc.L):
+        assert grid_err(eng.grid(msm.capi.GRID_E, l), sp.grid("e", l)) < TOL, l
+    assert np.abs(en - ref["energies"]).max() < TOL * np.abs(ref["energies"][:6]).max()
+    assert rel_rms(acc.cpu().numpy(), ref["acc"]) < TOL
+    eng.close()
+    sp.close()
+
+
 def test_eval_enqueue(msm, torch):
     """The non-synchronising entry point: several evaluations queued back to back, energies in pinned slots."""
     N, A = 30000, (1.0, 1.0, 1.0)
@@ -507,3 +532,65 @@ def test_direct_large(msm, torch):
     uo2, acco2 = O.direct(r2, q)
     assert abs(u2 - uo2) <= 1e-12 * np.abs(acco2).max()
     assert rel_rms(acc2, acco2) < TOL
+
+
+@pytest.mark.parametrize("name", ["NaClN8", "changaN8", "NaClN64", "changaN64", "changaN512"])
+def test_ewald_classical_matches_reference_output(msm, torch, name):
+    """ewaldClassical() on the GPU against the total the reference's own program printed for the same file and
+    arguments (tests/golden/ewaldClassical_*.json), and against the CPU restatement.  The changa totals are what
+    is left of components eight orders of magnitude larger, so the tolerance is 1e-12 of the largest component."""
+    fx = O.golden("ewaldClassical_%s.json" % name)
+    _, alpha, cd, cf = fx["args"]
+    _, r, q, A = system(name)
+    u = msm.ewaldClassical(r, q, A, alpha, cd, cf)
+    u5, _, _ = msm.ewald(r, q, A, alpha, cd, cf, literal=True, want_grad=False)
+    assert u == u5[4]
+    scale = np.abs(u5[:4]).max()
+    assert abs(u - fx["total"]) <= 1e-12 * scale, (u, fx["total"], u5)
+    r = np.ascontiguousarray(r)
+    uo = O.lib().or_ewald_classical(r.ctypes.data_as(O._dp), q.ctypes.data_as(O._dp), len(q), A[0], A[1], A[2],
+                                    float(alpha), float(cd), float(cf))
+    assert abs(u - uo) <= 1e-12 * scale
+
+
+def test_ewald_full_sum(msm, torch):
+    """The converged Ewald sum (nearest image, cube of wave vectors) against the CPU oracle: energy components,
+    potential gradient at every particle, a slice of particles, independence of the splitting parameter, and
+    the pair of a charge with its own images in a non-cubic cell."""
+    N, A = 1500, (1.0, 1.3, 0.8)
+    r, q = O.neutral_system(N, A, seed=5)
+    q = q * (1.0 + 0.25 * np.sin(np.arange(N)))          # not neutral: the background term takes part
+    alpha, rcut, kcut = 14.0, 0.4, 26
+    uo, ao = O.ewald(r, q, A, alpha, rcut, kcut, nthreads=8)
+    u5, phi, grad = msm.ewald(r, q, A, alpha, rcut, kcut)
+    assert abs(u5[4] - uo) < 1e-12 * abs(uo)
+    assert abs(u5[:4].sum() - u5[4]) < 1e-12 * abs(u5).max()
+    assert abs(0.5 * float((torch.as_tensor(q, device="cuda:0") * phi).sum()) - u5[4]) < 1e-12 * abs(u5).max()
+    assert rel_rms(grad.cpu().numpy(), ao) < 1e-12
+    # a slice sees the same potentials, and the slices' energies add up
+    ua, pa, ga = msm.ewald(r, q, A, alpha, rcut, kcut, 0, 700)
+    ub, pb, gb = msm.ewald(r, q, A, alpha, rcut, kcut, 700, N)
+    assert torch.equal(torch.cat([pa, pb]), phi) and torch.equal(torch.cat([ga, gb]), grad)
+    assert abs(ua[4] + ub[4] - u5[4]) < 1e-12 * abs(u5).max()
+    # two converged splittings (erfc(alpha rcut) and exp(-(pi k/alpha)^2) below 1e-14 along the longest edge), same sum
+    u5a, _, grada = msm.ewald(r, q, A, 14.0, 0.4, 34)
+    u5b, _, gradb = msm.ewald(r, q, A, 15.5, 0.4, 38)
+    assert abs(u5b[4] - u5a[4]) < 1e-11 * abs(u5a[4]) and rel_rms(gradb.cpu().numpy(), grada.cpu().numpy()) < 1e-11
+    # bad arguments are refused
+    with pytest.raises(msm.MsmAmdError):
+        msm.ewald(r, q, A, alpha, 0.41, kcut)            # beyond half the shortest edge (0.8 / 2)
+
+
+def test_ewald_agrees_with_msm_at_scale(msm, torch):
+    """At a size the CPU oracle cannot reach: the GPU Ewald sum against the MSM evaluation of the same system
+    (error of the MSM at abar = 6, p = 6 on a grid of half the usual spacing, far above the Ewald error)."""
+    N, A = 200000, (1.0, 1.0, 1.0)
+    r, q = O.neutral_system(N, A, seed=9)
+    alpha = 5.6 / 0.12
+    u5, phi, grad = msm.ewald(r, q, A, alpha, 0.12, int(np.ceil(5.6 * alpha / np.pi)), 0, 2048)
+    d0 = msm.plan_auto(N, A, 6, 10, 6.0, 0)
+    eng = msm.Engine(d0)
+    en, acc = eng.eval(r, q)
+    err = rel_rms(acc[:2048].cpu().numpy(), grad.cpu().numpy())
+    assert err < 2e-4, err
+    eng.close()

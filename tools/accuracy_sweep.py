@@ -1,38 +1,44 @@
-"""Accuracy / cost sweep of the periodic MSM against a full Ewald sum (cutoff abar x spline order p x grid).
+"""Accuracy / cost sweep of the periodic MSM against a converged Ewald sum (cutoff abar x spline order p x grid).
 
-    python tools/accuracy_sweep.py [N] [nsub]
+    python tools/accuracy_sweep.py [N]
 
-One charge-neutral random system; the reference values are a converged Ewald sum (CPU, oracle/ewald_oracle.c:
-real and reciprocal parts with image loops) for the first nsub particles.  For every sweep point the GPU
-evaluates the whole system; reported are the force RMS error sqrt(sum|f-f_ref|^2 / sum|f_ref|^2) over the subset,
-the relative error of the subset's energy share u_i = 1/2 q_i phi_i ... (not available per particle from the
-engine, so the total energy is compared with the Ewald total instead), and the time per evaluation.
+One charge-neutral random system; the reference is the Ewald sum of the same system on the GPU
+(msm_amd_ewald_device: potential gradient at every particle and the total energy).  For every sweep point the GPU
+evaluates the whole system; reported are the force RMS error sqrt(sum|f-f_ref|^2 / sum|f_ref|^2) over all particles,
+the relative error of the total energy, and the time per evaluation.
 """
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import msm_amd
-import oracle_lib as O
+from bench import make_system
 
 
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-    nsub = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    nsub = N
     A = (1.0, 1.0, 1.0)
-    r, q = O.neutral_system(N, A, seed=20261111 + 4)
+    r, q = make_system(N, 20261111 + 4)
     lib = msm_amd.load()
-    ht = (1.0 / N) ** (1.0 / 3.0)
-    t0 = time.time()
-    # Ewald parameters: erfc(alpha rcut) and exp(-(pi k / alpha)^2) both below 1e-13
-    alpha = 5.6 / 0.25
-    uE, aE = O.ewald(r, q, A, alpha=alpha, rcut=0.25, kcut=int(np.ceil(5.6 * alpha / np.pi)), nsub=N if N <= 20000 else nsub,
-                     nthreads=16)
-    have_energy = N <= 20000
-    aE = aE[:nsub]
-    print("# N=%d nsub=%d Ewald reference %.1f s (energy reference: %s)" % (N, nsub, time.time() - t0, have_energy), flush=True)
     rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
+    # Ewald parameters: erfc(alpha rcut) and exp(-(pi k / alpha)^2) both below 1e-13; particles sorted by cell so
+    # that the particles of a wave share their partners
+    rcut = 0.25
+    alpha = 5.6 / rcut
+    nb = 32
+    cell = [(rd[:, d] * nb).long().clamp_(0, nb - 1) for d in range(3)]
+    perm = torch.argsort((cell[2] * nb + cell[1]) * nb + cell[0])
+    torch.cuda.synchronize()
+    t0 = time.time()
+    u5, _, gs = msm_amd.ewald(rd[perm], qd[perm], A, alpha, rcut, int(np.ceil(5.6 * alpha / np.pi)))
+    torch.cuda.synchronize()
+    aE = torch.empty_like(gs)
+    aE[perm] = gs
+    aE = aE.cpu().numpy()
+    uE = float(u5[4])
+    have_energy = True
+    print("# N=%d Ewald reference on the GPU %.2f s, total energy %.12e" % (N, time.time() - t0, uE), flush=True)
     rows = []
     for fine in (1, 2):
         for p in (4, 6):
