@@ -125,6 +125,8 @@ void direct(int N, double *r, double *q, double *ureal, double *freal);
  * printing the reason if no GPU is visible or a HIP call fails. */
 double ewaldClassical(double *r, double *q, int n, double Lx, double Ly, double Lz, double alpha, double cutoffDirect,
                       double cutoffFourier);
+/* replaces ewaldClassicalRunner(), msm/ewaldClassical.h:5, msm/ewaldClassical.c:111-123: data file in, total on stdout */
+void ewaldClassicalRunner(char *dataFile, double alpha, double cutoffDirect, double cutoffFourier);
 
 /* parameter helpers, msm/msmLibrary.h:191-192,238-247 / msm/msmLibrary.c:3,31,46,69,110,283 */
 double mylog2(double x);

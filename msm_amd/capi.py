@@ -121,6 +121,7 @@ SIGNATURES = {
     "msm_amd_op_convolve": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "direct": (None, [C.c_int, _dp, _dp, _dp, _dp]),
     "ewaldClassical": (C.c_double, [_dp, _dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "ewaldClassicalRunner": (None, [C.c_char_p, C.c_double, C.c_double, C.c_double]),
     "msm_amd_ewald_work_doubles": (C.c_longlong, [C.c_int, C.c_double, C.c_int]),
     "msm_amd_ewald_device": (C.c_int, [C.c_int, _vp, _vp, _dp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
                                        _vp, _vp, _vp, _vp, _dp]),

@@ -377,3 +377,18 @@ extern "C" double ewaldClassical(double *r, double *q, int n, double Lx, double 
     fprintf(stderr, "\033[1;34m %12.4e %12.4e %12.4e %12.4e = %12.4e \033[0m\n", u[0], u[1], u[2], u[3], u[4]);
     return u[4];
 }
+
+// replaces ewaldClassicalRunner(), msm/ewaldClassical.h:5, msm/ewaldClassical.c:111-123: read the data file, print the
+// total energy with the reference's format
+extern "C" void ewaldClassicalRunner(char *dataFile, double alpha, double cutoffDirect, double cutoffFourier) {
+    double *r = nullptr, *q = nullptr, Lx, Ly, Lz;
+    int n = 0;
+    if (data_read(dataFile, &q, &r, &n, &Lx, &Ly, &Lz) != 0 || n < 1) {
+        fprintf(stderr, "ewaldClassicalRunner: cannot read %s\n", dataFile ? dataFile : "(null)");
+        return;
+    }
+    const double potential = ewaldClassical(r, q, n, Lx, Ly, Lz, alpha, cutoffDirect, cutoffFourier);
+    printf("%20.15e\n", potential);
+    free(r);
+    free(q);
+}

@@ -122,6 +122,7 @@ struct TileSrc {
     int cluster_order;
     double scale[3];     // slot coordinate -> grid units
 };
+extern bool anterp_cols_enabled;
 bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, double *scratch,
                          int *tile_used, double *grid);
 void launch_interp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, const double *egrid,

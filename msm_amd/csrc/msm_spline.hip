@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_anterp_tiles(TileSrc S, SplineParams sp
     constexpr int R = AT + P - 1, R3 = R * R * R;
     extern __shared__ double lds[]; // 4 copies of the node block
     __shared__ int any_particle;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     double *__restrict__ mine = lds + wave * R3;
     const int tile = blockIdx.x;
     const int tx = tile % tl.nt[0], ty = (tile / tl.nt[0]) % tl.nt[1], tz = tile / (tl.nt[0] * tl.nt[1]);
@@ -138,6 +138,123 @@ __global__ __launch_bounds__(256) void k_anterp_tiles(TileSrc S, SplineParams sp
     __syncthreads();
     double *__restrict__ out = scratch + (size_t)tile * R3;
     for (int t = threadIdx.x; t < R3; t += 256) out[t] = ((lds[t] + lds[R3 + t]) + lds[2 * R3 + t]) + lds[3 * R3 + t];
+}
+
+// The same spreading for particles in cluster order, accumulated in registers.  The particles of a tile come as
+// runs, one per column of KX x KY cells, sorted by z.  All particles of a column reach the same
+// (KX + P - 1) x (KY + P - 1) nodes in x and y: these are the lanes, each with the whole z extent of the tile's node
+// block (8 + P - 1 sums) in registers.  A particle in cell (dx, dy, cz) of its column adds w_x w_y w_z q to P
+// consecutive sums starting at cz; dx and dy only select which polynomial piece a lane evaluates (zero outside
+// the particle's support), and the walk visits the z cells in turn so that the register indices are fixed at
+// compile time.  The LDS block is touched once per column instead of P times per particle.
+template <int P, int KX, int KY>
+__global__ __launch_bounds__(256) void k_anterp_cols(TileSrc S, SplineParams sp, TileGeom tl, double *__restrict__ scratch,
+                                                     int *__restrict__ tile_used) {
+    constexpr int R = AT + P - 1, R3 = R * R * R, FX = KX + P - 1, FY = KY + P - 1;
+    constexpr int MAXRUNS = (AT / KX) * (AT / KY);
+    static_assert(FX * FY <= 64, "one lane per (x, y) node of a column's support");
+    extern __shared__ double lds[]; // the node block of the tile
+    __shared__ int sbnd[MAXRUNS][AT + 1]; // per run: the slots at which the z cells of the tile begin
+    __shared__ int any_particle;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int tile = blockIdx.x;
+    const int tx = tile % tl.nt[0], ty = (tile / tl.nt[0]) % tl.nt[1], tz = tile / (tl.nt[0] * tl.nt[1]);
+    const int x0 = tx * AT, y0 = ty * AT, z0 = tz * AT;
+    const int nxc = min(AT, sp.M[0] - x0), nyc = min(AT, sp.M[1] - y0), nzc = min(AT, sp.M[2] - z0);
+    const int ncxt = nxc / KX, nruns = ncxt * (nyc / KY);
+    const int kz = S.cg.kz, nzf = S.cg.nzf;
+    if (threadIdx.x == 0) any_particle = 0;
+    // all the bookkeeping of the tile's runs up front, one (run, z cell) per thread: the waves then never wait for
+    // a chain of dependent index loads between two runs
+    for (int t = threadIdx.x; t < nruns * (AT + 1); t += 256) {
+        const int run = t / (AT + 1), c = t % (AT + 1);
+        const int col = cl_col(S.cg, x0 / KX + run % ncxt, y0 / KY + run / ncxt), bb = col * nzf;
+        // slot of a particle = CL_G * (first cluster of its column) + its rank inside the column
+        sbnd[run][c] = CL_G * S.clstart[col] - S.start[bb] + S.start[bb + (z0 + min(c, nzc)) * kz];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nruns && sbnd[threadIdx.x][AT] > sbnd[threadIdx.x][0]) any_particle = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_used[tile] = any_particle;
+    if (!any_particle) return;
+    for (int t = threadIdx.x; t < R3; t += 256) lds[t] = 0.0;
+    __syncthreads();
+    const int a = lane % FX, b = lane / FX;
+    const bool active = lane < FX * FY;
+    double cx[KX][P], cy[KY][P];
+#pragma unroll
+    for (int d = 0; d < KX; d++)
+#pragma unroll
+        for (int n = 0; n < P; n++) cx[d][n] = (a - d >= 0 && a - d < P) ? sp.piece[a - d][n] : 0.0;
+#pragma unroll
+    for (int d = 0; d < KY; d++)
+#pragma unroll
+        for (int n = 0; n < P; n++) cy[d][n] = (b - d >= 0 && b - d < P) ? sp.piece[b - d][n] : 0.0;
+    const double4 none = make_double4(0, 0, 0, 0);
+    // the first 64 particles of a run are requested while the run before it is being spread
+    double4 pre = none;
+    if (wave < nruns && sbnd[wave][0] + lane < sbnd[wave][AT]) pre = S.ps[sbnd[wave][0] + lane];
+    // The four waves take four runs at a time and then add their sums to the block one wave after the other, so
+    // that every node receives its terms in a fixed order from a single copy of the block (a copy per wave would
+    // leave room for two workgroups per CU only).
+    for (int run0 = 0; run0 < nruns; run0 += 4) {
+        const int run = min(run0 + wave, nruns - 1); // a wave without a run of its own repeats the last one, unused
+        const bool mine = run0 + wave < nruns;
+        const int colx = x0 / KX + run % ncxt, coly = y0 / KY + run / ncxt;
+        int bnd[AT + 1];
+#pragma unroll
+        for (int c = 0; c <= AT; c++) bnd[c] = mine ? sbnd[run][c] : 0;
+        const double4 first64 = pre;
+        pre = none;
+        if (run + 4 < nruns && sbnd[run + 4][0] + lane < sbnd[run + 4][AT]) pre = S.ps[sbnd[run + 4][0] + lane];
+        double acc[R];
+#pragma unroll
+        for (int z = 0; z < R; z++) acc[z] = 0.0;
+        for (int sb = bnd[0]; sb < bnd[AT]; sb += 64) {
+            const int cnt = min(64, bnd[AT] - sb);
+            const int slot = sb + lane;
+            double4 ptl = first64;
+            if (sb > bnd[0]) ptl = lane < cnt ? S.ps[slot] : none;
+            int cz = 0;
+#pragma unroll
+            for (int c = 1; c < AT; c++) cz += slot >= bnd[c];
+            const double ux = ptl.x * S.scale[0], uy = ptl.y * S.scale[1], uz = ptl.z * S.scale[2];
+            // cell inside the column, kept there whatever the last bit of the product did; the z cell is the one the
+            // sort put the particle in
+            const int dx = min(max((int)ux - colx * KX, 0), KX - 1), dy = min(max((int)uy - coly * KY, 0), KY - 1);
+            const double lfx = ux - (double)(colx * KX + dx), lfy = uy - (double)(coly * KY + dy), lfz = uz - (double)(z0 + cz);
+            const int ldxy = dx + KX * dy;
+            double lwz[P];
+#pragma unroll
+            for (int cc = 0; cc < P; cc++) lwz[cc] = ptl.w * piece_eval<P>(sp.piece[cc], lfz);
+#pragma unroll
+            for (int c = 0; c < AT; c++) {
+                const int k0 = max(bnd[c], sb) - sb, k1 = min(bnd[c + 1], sb + cnt) - sb;
+                for (int k = k0; k < k1; k++) {
+                    const double fx = readlane_d(lfx, k), fy = readlane_d(lfy, k);
+                    const int dxy = __builtin_amdgcn_readlane(ldxy, k);
+                    double wx, wy;
+                    if (KX == 1 || dxy % KX == 0) wx = piece_eval<P>(cx[0], fx);
+                    else wx = piece_eval<P>(cx[KX - 1], fx);
+                    if (KY == 1 || dxy / KX == 0) wy = piece_eval<P>(cy[0], fy);
+                    else wy = piece_eval<P>(cy[KY - 1], fy);
+                    const double wxy = wx * wy;
+#pragma unroll
+                    for (int cc = 0; cc < P; cc++) acc[c + cc] = fma(wxy, readlane_d(lwz[cc], k), acc[c + cc]);
+                }
+            }
+        }
+        for (int w = 0; w < 4; w++) {
+            if (w == wave && active && bnd[AT] > bnd[0]) {
+                double *dst = lds + ((coly * KY - y0) + b) * R + (colx * KX - x0) + a;
+#pragma unroll
+                for (int z = 0; z < R; z++) dst[z * R * R] += acc[z];
+            }
+            __syncthreads();
+        }
+    }
+    double *__restrict__ out = scratch + (size_t)tile * R3;
+    for (int t = threadIdx.x; t < R3; t += 256) out[t] = lds[t];
 }
 
 // (tile, index inside the tile's node block) pairs that hold contributions to node x of one axis
@@ -284,11 +401,35 @@ void launch_interp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &s
     else hipLaunchKernelGGL((k_interp_tiles<6>), dim3(tl.ntiles), dim3(256), 0, st, S, sp, tl, egrid, acc);
 }
 
+bool anterp_cols_enabled = true; // A/B switch: register accumulation per column (cluster order, columns up to 2 x 2 cells)
+
 bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, double *scratch,
                          int *tile_used, double *grid) {
     const size_t n = (size_t)sp.M[0] * sp.M[1] * sp.nz;
     const int gb = (int)((n + 255) / 256);
     static bool attr4 = false, attr6 = false;
+    if (sp.p == 6 && S.cluster_order && S.cg.kx >= 1 && S.cg.kx <= 2 && S.cg.ky >= 1 && S.cg.ky <= 2 && anterp_cols_enabled) {
+        // order 6, columns of at most 2 x 2 cells: sums kept in registers (at order 4 a particle's 64 nodes are one LDS
+        // update of a full wave, which is faster)
+        const int R = AT + sp.p - 1;
+        const size_t bytes = sizeof(double) * R * R * R;
+        static bool attr[2][2][2] = {};
+        const void *kern = nullptr;
+        void (*k)(TileSrc, SplineParams, TileGeom, double *, int *) = nullptr;
+#define PICK(P, KX, KY) if (sp.p == P && S.cg.kx == KX && S.cg.ky == KY) k = k_anterp_cols<P, KX, KY>;
+        PICK(6, 1, 1) PICK(6, 1, 2) PICK(6, 2, 1) PICK(6, 2, 2)
+#undef PICK
+        kern = (const void *)k;
+        bool &done = attr[sp.p == 6][S.cg.kx - 1][S.cg.ky - 1];
+        if (k && (done || hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess)) {
+            done = true;
+            hipLaunchKernelGGL(k, dim3(tl.ntiles), dim3(256), bytes, st, S, sp, tl, scratch, tile_used);
+            if (sp.p == 4) hipLaunchKernelGGL((k_anterp_combine<4>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
+            else hipLaunchKernelGGL((k_anterp_combine<6>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
+            return true;
+        }
+        (void)hipGetLastError();
+    }
     if (sp.p == 4) {
         const size_t bytes = 4 * sizeof(double) * (AT + 3) * (AT + 3) * (AT + 3);
         auto kern = k_anterp_tiles<4>;

@@ -204,14 +204,17 @@ def test_anterpolation_tiled(msm, torch, p, M):
     rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
     want = sp.anterpolate(r, q)
     got = {}
-    for tiled in (1, 0):
+    # tiled with sums per column in registers (order 6), tiled with one LDS update per particle and plane, gather
+    for key, (tiled, cols) in {1: (1, 1), 2: (1, 0), 0: (0, 0)}.items():
         eng.set_option("anterp_tiled", tiled)
+        eng.set_option("anterp_cols", cols)
         eng.stage_bin(rd, qd)
         eng.stage_anterpolate()
-        got[tiled] = eng.grid(msm.capi.GRID_Q, 0)
-        assert grid_err(got[tiled], want) < TOL, tiled
-    assert grid_err(got[1], got[0]) < 1e-13
+        got[key] = eng.grid(msm.capi.GRID_Q, 0)
+        assert grid_err(got[key], want) < TOL, key
+    assert grid_err(got[1], got[0]) < 1e-13 and grid_err(got[2], got[0]) < 1e-13
     eng.set_option("anterp_tiled", 1)
+    eng.set_option("anterp_cols", 1)
     eng.stage_bin(rd, qd)
     eng.stage_anterpolate()
     assert np.array_equal(eng.grid(msm.capi.GRID_Q, 0), got[1])   # reproducible
