@@ -597,3 +597,35 @@ def test_ewald_agrees_with_msm_at_scale(msm, torch):
     err = rel_rms(acc[:2048].cpu().numpy(), grad.cpu().numpy())
     assert err < 2e-4, err
     eng.close()
+
+
+def test_command_line_drivers(msm, tmp_path):
+    """The restated mains of msm/msmPeriodic.c:1423 and msm/ewaldClassical.c:125, linked against the library: same
+    argv, same stdout (the potential with %20.15e), same msm.pot / msm.acc files, on a file in the reference's format."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = [os.path.join(root, "drivers", n) for n in ("msmPeriodic", "ewaldClassical")]
+    if not all(os.path.exists(e) for e in exe):   # normally built beforehand by __graft_entry__.build()
+        subprocess.run(["make", "-C", os.path.join(root, "msm_amd", "csrc"), "driver"], capture_output=True, timeout=300)
+    if not all(os.path.exists(e) for e in exe):
+        pytest.fail("drivers are not built: make -C msm_amd/csrc driver")
+    fx, r, q, A = system("NaClN8")
+    data = tmp_path / "NaClN8.ini"
+    with open(data, "w") as f:
+        f.write("%.17g %.17g %.17g\n%d\n" % (A[0], A[1], A[2], len(q)))
+        for i in range(len(q)):
+            f.write("%.17g %.17g %.17g %.17g\n" % (r[i, 0], r[i, 1], r[i, 2], q[i]))
+    out = subprocess.run([exe[0], str(data), "4", "10", "4"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    u = float(out.stdout.strip().split()[-1])
+    scale = max(abs(v) for v in fx["scalars"].values())
+    assert abs(u - fx["potential"]) <= TOL * scale
+    assert abs(float(open(tmp_path / "msm.pot").read()) - fx["potential"]) <= TOL * scale
+    acc = np.loadtxt(tmp_path / "msm.acc", skiprows=1).reshape(3, -1).T
+    assert np.abs(acc - np.array(fx["acc"]).reshape(-1, 3)).max() < 1e-10
+    fe = O.golden("ewaldClassical_NaClN8.json")
+    out = subprocess.run([exe[1], str(data)] + [str(a) for a in fe["args"][1:]], cwd=tmp_path, capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert abs(float(out.stdout.strip().split()[-1]) - fe["total"]) <= 1e-11 * abs(fe["total"])
+    assert "Classical" in out.stderr
