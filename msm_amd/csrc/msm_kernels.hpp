@@ -123,6 +123,7 @@ struct TileSrc {
     double scale[3];     // slot coordinate -> grid units
 };
 extern bool anterp_cols_enabled;
+extern int anterp_cols_waves;
 bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, double *scratch,
                          int *tile_used, double *grid);
 void launch_interp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, const double *egrid,

@@ -13,6 +13,8 @@
 
 #include "msm_amd.h"
 
+#include <algorithm>
+
 namespace msm {
 
 #define AT SPLINE_TILE
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void k_anterp_tiles(TileSrc S, SplineParams sp
 // the particle's support), and the walk visits the z cells in turn so that the register indices are fixed at
 // compile time.  The LDS block is touched once per column instead of P times per particle.
 template <int P, int KX, int KY>
-__global__ __launch_bounds__(256) void k_anterp_cols(TileSrc S, SplineParams sp, TileGeom tl, double *__restrict__ scratch,
+__global__ __launch_bounds__(1024) void k_anterp_cols(TileSrc S, SplineParams sp, TileGeom tl, double *__restrict__ scratch,
                                                      int *__restrict__ tile_used) {
     constexpr int R = AT + P - 1, R3 = R * R * R, FX = KX + P - 1, FY = KY + P - 1;
     constexpr int MAXRUNS = (AT / KX) * (AT / KY);
@@ -166,7 +168,8 @@ __global__ __launch_bounds__(256) void k_anterp_cols(TileSrc S, SplineParams sp,
     if (threadIdx.x == 0) any_particle = 0;
     // all the bookkeeping of the tile's runs up front, one (run, z cell) per thread: the waves then never wait for
     // a chain of dependent index loads between two runs
-    for (int t = threadIdx.x; t < nruns * (AT + 1); t += 256) {
+    const int nw = blockDim.x >> 6; // waves of the workgroup: 4 to 16, one run each at a time
+    for (int t = threadIdx.x; t < nruns * (AT + 1); t += blockDim.x) {
         const int run = t / (AT + 1), c = t % (AT + 1);
         const int col = cl_col(S.cg, x0 / KX + run % ncxt, y0 / KY + run / ncxt), bb = col * nzf;
         // slot of a particle = CL_G * (first cluster of its column) + its rank inside the column
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) void k_anterp_cols(TileSrc S, SplineParams sp,
     __syncthreads();
     if (threadIdx.x == 0) tile_used[tile] = any_particle;
     if (!any_particle) return;
-    for (int t = threadIdx.x; t < R3; t += 256) lds[t] = 0.0;
+    for (int t = threadIdx.x; t < R3; t += blockDim.x) lds[t] = 0.0;
     __syncthreads();
     const int a = lane % FX, b = lane / FX;
     const bool active = lane < FX * FY;
@@ -194,10 +197,10 @@ __global__ __launch_bounds__(256) void k_anterp_cols(TileSrc S, SplineParams sp,
     // the first 64 particles of a run are requested while the run before it is being spread
     double4 pre = none;
     if (wave < nruns && sbnd[wave][0] + lane < sbnd[wave][AT]) pre = S.ps[sbnd[wave][0] + lane];
-    // The four waves take four runs at a time and then add their sums to the block one wave after the other, so
+    // The waves take one run each at a time and then add their sums to the block one wave after the other, so
     // that every node receives its terms in a fixed order from a single copy of the block (a copy per wave would
     // leave room for two workgroups per CU only).
-    for (int run0 = 0; run0 < nruns; run0 += 4) {
+    for (int run0 = 0; run0 < nruns; run0 += nw) {
         const int run = min(run0 + wave, nruns - 1); // a wave without a run of its own repeats the last one, unused
         const bool mine = run0 + wave < nruns;
         const int colx = x0 / KX + run % ncxt, coly = y0 / KY + run / ncxt;
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) void k_anterp_cols(TileSrc S, SplineParams sp,
         for (int c = 0; c <= AT; c++) bnd[c] = mine ? sbnd[run][c] : 0;
         const double4 first64 = pre;
         pre = none;
-        if (run + 4 < nruns && sbnd[run + 4][0] + lane < sbnd[run + 4][AT]) pre = S.ps[sbnd[run + 4][0] + lane];
+        if (run + nw < nruns && sbnd[run + nw][0] + lane < sbnd[run + nw][AT]) pre = S.ps[sbnd[run + nw][0] + lane];
         double acc[R];
 #pragma unroll
         for (int z = 0; z < R; z++) acc[z] = 0.0;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256) void k_anterp_cols(TileSrc S, SplineParams sp,
                 }
             }
         }
-        for (int w = 0; w < 4; w++) {
+        for (int w = 0; w < nw; w++) {
             if (w == wave && active && bnd[AT] > bnd[0]) {
                 double *dst = lds + ((coly * KY - y0) + b) * R + (colx * KX - x0) + a;
 #pragma unroll
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256) void k_anterp_cols(TileSrc S, SplineParams sp,
         }
     }
     double *__restrict__ out = scratch + (size_t)tile * R3;
-    for (int t = threadIdx.x; t < R3; t += 256) out[t] = lds[t];
+    for (int t = threadIdx.x; t < R3; t += blockDim.x) out[t] = lds[t];
 }
 
 // (tile, index inside the tile's node block) pairs that hold contributions to node x of one axis
@@ -333,13 +336,16 @@ __global__ __launch_bounds__(256) void k_interp_tiles(TileSrc S, SplineParams sp
     __syncthreads();
     const int total = rowstart[nrows];
     if (total == 0) return;
+    // the tile's particles may be shared between gridDim.y workgroups (a rank that owns a thin slab has few tiles)
+    const int share = (total + gridDim.y - 1) / gridDim.y, idx_end = min(total, ((int)blockIdx.y + 1) * share);
+    if ((int)blockIdx.y * share >= total) return;
     for (int t = threadIdx.x; t < R3; t += 256) {
         const int lx = t % R, ly = (t / R) % R, lz = t / (R * R);
         const int gx = modp(x0 - (P / 2 - 1) + lx, Mx), gy = modp(y0 - (P / 2 - 1) + ly, My), gz = modp(z0 - (P / 2 - 1) + lz, Mz);
         blk[t] = e[((size_t)gz * My + gy) * Mx + gx];
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < total; idx += 256) {
+    for (int idx = blockIdx.y * share + threadIdx.x; idx < idx_end; idx += 256) {
         int lo = 0, hi = nrows; // row with rowstart[row] <= idx < rowstart[row+1]
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -397,10 +403,14 @@ __global__ __launch_bounds__(256) void k_interp_tiles(TileSrc S, SplineParams sp
 
 void launch_interp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, const double *egrid,
                          double *acc) {
-    if (sp.p == 4) hipLaunchKernelGGL((k_interp_tiles<4>), dim3(tl.ntiles), dim3(256), 0, st, S, sp, tl, egrid, acc);
-    else hipLaunchKernelGGL((k_interp_tiles<6>), dim3(tl.ntiles), dim3(256), 0, st, S, sp, tl, egrid, acc);
+    // gridDim.y > 1 shares a tile's particles between workgroups; measured slower even for a rank that owns a thin
+    // slab (every workgroup stages the tile's block of potentials again), so one workgroup per tile it is
+    const int ns = 1;
+    if (sp.p == 4) hipLaunchKernelGGL((k_interp_tiles<4>), dim3(tl.ntiles, ns), dim3(256), 0, st, S, sp, tl, egrid, acc);
+    else hipLaunchKernelGGL((k_interp_tiles<6>), dim3(tl.ntiles, ns), dim3(256), 0, st, S, sp, tl, egrid, acc);
 }
 
+int anterp_cols_waves = 0;        // waves per tile workgroup of the column kernel: 4, 8, 16, or 0 = by the share of owned planes
 bool anterp_cols_enabled = true; // A/B switch: register accumulation per column (cluster order, columns up to 2 x 2 cells)
 
 bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, double *scratch,
@@ -423,7 +433,10 @@ bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &s
         bool &done = attr[sp.p == 6][S.cg.kx - 1][S.cg.ky - 1];
         if (k && (done || hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess)) {
             done = true;
-            hipLaunchKernelGGL(k, dim3(tl.ntiles), dim3(256), bytes, st, S, sp, tl, scratch, tile_used);
+            // 4 waves per tile fill the chip when every tile has particles; a rank that owns a thin slab has few busy
+            // tiles and finishes sooner with 8 (more runs at a time, at the price of more flush phases)
+            const int nw = anterp_cols_waves ? anterp_cols_waves : (2 * sp.nz <= sp.M[2] ? 8 : 4);
+            hipLaunchKernelGGL(k, dim3(tl.ntiles), dim3(64 * nw), bytes, st, S, sp, tl, scratch, tile_used);
             if (sp.p == 4) hipLaunchKernelGGL((k_anterp_combine<4>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
             else hipLaunchKernelGGL((k_anterp_combine<6>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
             return true;
