@@ -155,7 +155,7 @@ __global__ __launch_bounds__(1024) void k_anterp_cols(TileSrc S, SplineParams sp
     constexpr int R = AT + P - 1, R3 = R * R * R, FX = KX + P - 1, FY = KY + P - 1;
     constexpr int MAXRUNS = (AT / KX) * (AT / KY);
     static_assert(FX * FY <= 64, "one lane per (x, y) node of a column's support");
-    extern __shared__ double lds[]; // the node block of the tile
+    extern __shared__ __align__(16) double lds[]; // the node block of the tile, then one staging area per wave
     __shared__ int sbnd[MAXRUNS][AT + 1]; // per run: the slots at which the z cells of the tile begin
     __shared__ int any_particle;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -182,6 +182,8 @@ __global__ __launch_bounds__(1024) void k_anterp_cols(TileSrc S, SplineParams sp
     if (!any_particle) return;
     for (int t = threadIdx.x; t < R3; t += blockDim.x) lds[t] = 0.0;
     __syncthreads();
+    constexpr int REC = ((2 + P + 1) + 1) / 2 * 2; // doubles per staged particle record (even: 16-byte reads)
+    double *__restrict__ stage = lds + ((R3 + 1) / 2 * 2) + wave * (64 * REC);
     const int a = lane % FX, b = lane / FX;
     const bool active = lane < FX * FY;
     double cx[KX][P], cy[KY][P];
@@ -226,16 +228,28 @@ __global__ __launch_bounds__(1024) void k_anterp_cols(TileSrc S, SplineParams sp
             // sort put the particle in
             const int dx = min(max((int)ux - colx * KX, 0), KX - 1), dy = min(max((int)uy - coly * KY, 0), KY - 1);
             const double lfx = ux - (double)(colx * KX + dx), lfy = uy - (double)(coly * KY + dy), lfz = uz - (double)(z0 + cz);
-            const int ldxy = dx + KX * dy;
-            double lwz[P];
+            // Every lane leaves what the others need of its particle (offsets inside the cell, the P z weights times
+            // the charge, the cell inside the column) in the wave's staging area; the walk below reads one record per
+            // particle with all lanes on the same address (broadcast reads), which costs far fewer instructions than
+            // fetching the values lane by lane with v_readlane.
+            __builtin_amdgcn_wave_barrier();
+            double *rec_mine = stage + lane * REC;
+            rec_mine[0] = lfx;
+            rec_mine[1] = lfy;
 #pragma unroll
-            for (int cc = 0; cc < P; cc++) lwz[cc] = ptl.w * piece_eval<P>(sp.piece[cc], lfz);
+            for (int cc = 0; cc < P; cc++) rec_mine[2 + cc] = ptl.w * piece_eval<P>(sp.piece[cc], lfz);
+            rec_mine[2 + P] = __hiloint2double(0, dx + KX * dy);
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int c = 0; c < AT; c++) {
                 const int k0 = max(bnd[c], sb) - sb, k1 = min(bnd[c + 1], sb + cnt) - sb;
                 for (int k = k0; k < k1; k++) {
-                    const double fx = readlane_d(lfx, k), fy = readlane_d(lfy, k);
-                    const int dxy = __builtin_amdgcn_readlane(ldxy, k);
+                    const double *rec = stage + k * REC;
+                    const double fx = rec[0], fy = rec[1];
+                    const int dxy = __builtin_amdgcn_readfirstlane(__double2loint(rec[2 + P]));
+                    double wz[P];
+#pragma unroll
+                    for (int cc = 0; cc < P; cc++) wz[cc] = rec[2 + cc];
                     double wx, wy;
                     if (KX == 1 || dxy % KX == 0) wx = piece_eval<P>(cx[0], fx);
                     else wx = piece_eval<P>(cx[KX - 1], fx);
@@ -243,7 +257,7 @@ __global__ __launch_bounds__(1024) void k_anterp_cols(TileSrc S, SplineParams sp
                     else wy = piece_eval<P>(cy[KY - 1], fy);
                     const double wxy = wx * wy;
 #pragma unroll
-                    for (int cc = 0; cc < P; cc++) acc[c + cc] = fma(wxy, readlane_d(lwz[cc], k), acc[c + cc]);
+                    for (int cc = 0; cc < P; cc++) acc[c + cc] = fma(wxy, wz[cc], acc[c + cc]);
                 }
             }
         }
@@ -411,6 +425,7 @@ void launch_interp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &s
 }
 
 int anterp_cols_waves = 0;        // waves per tile workgroup of the column kernel: 4, 8, 16, or 0 = by the share of owned planes
+bool anterp_cols_order4 = false;  // A/B: the column kernel at order 4 too
 bool anterp_cols_enabled = true; // A/B switch: register accumulation per column (cluster order, columns up to 2 x 2 cells)
 
 bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, double *scratch,
@@ -418,16 +433,16 @@ bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &s
     const size_t n = (size_t)sp.M[0] * sp.M[1] * sp.nz;
     const int gb = (int)((n + 255) / 256);
     static bool attr4 = false, attr6 = false;
-    if (sp.p == 6 && S.cluster_order && S.cg.kx >= 1 && S.cg.kx <= 2 && S.cg.ky >= 1 && S.cg.ky <= 2 && anterp_cols_enabled) {
+    if ((sp.p == 6 || anterp_cols_order4) && S.cluster_order && S.cg.kx >= 1 && S.cg.kx <= 2 && S.cg.ky >= 1 && S.cg.ky <= 2 && anterp_cols_enabled) {
         // order 6, columns of at most 2 x 2 cells: sums kept in registers (at order 4 a particle's 64 nodes are one LDS
         // update of a full wave, which is faster)
         const int R = AT + sp.p - 1;
-        const size_t bytes = sizeof(double) * R * R * R;
+        const size_t bytes = sizeof(double) * ((size_t)(R * R * R + 1) / 2 * 2 + (size_t)16 * 64 * 10); // the most any launch asks for
         static bool attr[2][2][2] = {};
         const void *kern = nullptr;
         void (*k)(TileSrc, SplineParams, TileGeom, double *, int *) = nullptr;
 #define PICK(P, KX, KY) if (sp.p == P && S.cg.kx == KX && S.cg.ky == KY) k = k_anterp_cols<P, KX, KY>;
-        PICK(6, 1, 1) PICK(6, 1, 2) PICK(6, 2, 1) PICK(6, 2, 2)
+        PICK(4, 1, 1) PICK(4, 1, 2) PICK(4, 2, 1) PICK(4, 2, 2) PICK(6, 1, 1) PICK(6, 1, 2) PICK(6, 2, 1) PICK(6, 2, 2)
 #undef PICK
         kern = (const void *)k;
         bool &done = attr[sp.p == 6][S.cg.kx - 1][S.cg.ky - 1];
@@ -436,7 +451,9 @@ bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &s
             // 4 waves per tile fill the chip when every tile has particles; a rank that owns a thin slab has few busy
             // tiles and finishes sooner with 8 (more runs at a time, at the price of more flush phases)
             const int nw = anterp_cols_waves ? anterp_cols_waves : (2 * sp.nz <= sp.M[2] ? 8 : 4);
-            hipLaunchKernelGGL(k, dim3(tl.ntiles), dim3(64 * nw), bytes, st, S, sp, tl, scratch, tile_used);
+            const int rec = (2 + sp.p + 1 + 1) / 2 * 2;
+            const size_t dyn = sizeof(double) * ((size_t)(R * R * R + 1) / 2 * 2 + (size_t)nw * 64 * rec);
+            hipLaunchKernelGGL(k, dim3(tl.ntiles), dim3(64 * nw), dyn, st, S, sp, tl, scratch, tile_used);
             if (sp.p == 4) hipLaunchKernelGGL((k_anterp_combine<4>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
             else hipLaunchKernelGGL((k_anterp_combine<6>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
             return true;
