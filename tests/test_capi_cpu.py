@@ -160,3 +160,10 @@ def test_no_cpu_fallback(msm):
     assert b"no CPU path" in msm.load().msm_amd_last_error()
     with pytest.raises(msm.MsmAmdError):
         msm.Engine(d)
+    # the host-pointer entry points of the other drivers fail loudly too: no result, the reason on stderr
+    r = np.random.default_rng(1).random((8, 3))
+    q = np.where(np.arange(8) % 2 == 0, 1.0, -1.0)
+    u = msm.ewaldClassical(r, q, (1.0, 1.0, 1.0), 6.0, 10.0, 4.0)
+    assert np.isnan(u) and b"no CPU path" in msm.load().msm_amd_last_error()
+    u, f = msm.direct(r, q)
+    assert u == 0.0 and not f.any() and b"no CPU path" in msm.load().msm_amd_last_error()
