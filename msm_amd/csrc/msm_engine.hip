@@ -76,6 +76,10 @@ struct msm_amd_handle {
     int opt_anterp_tiled = 1;
     // second stream: the grid pipeline runs beside the list build and the pair kernel
     hipStream_t stream_b = nullptr;
+    hipStream_t stream_g = nullptr; // coarse-level branch of the grid stage
+    hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr;
+    int opt_grid_streams = 0; // measured: slower (1.68 vs 1.65 ms at 1M; the chain of small kernels does not get CUs while the
+                              // level-0 convolution runs), and cross-stream waits stalled with 4 processes sharing one GPU
     hipEvent_t ev_fork = nullptr, ev_pairs = nullptr, ev_join = nullptr;
     int opt_overlap = 0; // measured: +5 % evaluations/s, but the pair kernel's workgroups starve the large convolution blocks
     int opt_transfer_fused = 0;              // 0 separable passes (faster at every size measured), 1 fused, 2 fused up to opt_transfer_fused_max fine nodes
@@ -387,6 +391,11 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     hipFree(h->d_energies);
     if (h->h_energies) hipHostFree(h->h_energies);
     hipFree(h->s_r); hipFree(h->s_q); hipFree(h->s_acc);
+    if (h->stream_g) {
+        hipStreamSynchronize(h->stream_g);
+        hipEventDestroy(h->ev_gfork); hipEventDestroy(h->ev_gjoin);
+        hipStreamDestroy(h->stream_g);
+    }
     if (h->stream_b) {
         hipStreamSynchronize(h->stream_b);
         hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_pairs); hipEventDestroy(h->ev_join);
@@ -432,6 +441,7 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "anterp_cols_order4")) { anterp_cols_order4 = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "anterp_cols")) { anterp_cols_enabled = value != 0; return MSM_AMD_OK; } // process-wide A/B switch
     if (!strcmp(key, "overlap")) { h->opt_overlap = value; return MSM_AMD_OK; }
+    if (!strcmp(key, "grid_streams")) { h->opt_grid_streams = value; return MSM_AMD_OK; }
     if (!strcmp(key, "transfer_fused")) { h->opt_transfer_fused = value; return MSM_AMD_OK; }
     if (!strcmp(key, "transfer_fused_max")) { h->opt_transfer_fused_max = value; return MSM_AMD_OK; }
     set_error("unknown option %s", key);
@@ -582,43 +592,21 @@ static void prolong_level_add(msm_amd_handle *h, int l, const double *coarse, do
     launch_prolong_axis(h->stream, h->tmpA, fine, c2, 0, p, h->hp.J, 1);
 }
 
-extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
-    if (!h) return MSM_AMD_EINVAL;
-    const msm_amd_plan_desc &d = h->hp.d;
-    const int L = d.L, p = d.p;
+namespace {
+struct PlaneRange { int l, z0, nz; };
+}
+
+// convolutions of the given plane ranges on the handle's current stream: the large ones share one launch of the
+// multi-level tiled kernel, the rest go one by one
+static void convolve_ranges(msm_amd_handle *h, const std::vector<PlaneRange> &ranges) {
     hipStream_t st = h->stream;
-    mark(h, T_RES);
-    for (int l = 0; l + 1 < L; l++) restrict_level(h, l, h->gq[l], h->gq[l + 1]);
-    mark(h, T_CONV);
-    // plane ranges to convolve per level: everything, except on a slab rank's level 0, where the potentials are
-    // needed on the owned planes plus p/2 planes either side (interpolation support) and the other planes of
-    // ge[0] are left at zero
-    struct Range { int l, z0, nz; };
-    std::vector<Range> ranges;
-    for (int l = 0; l < L; l++) {
-        if (l == 0 && d.nzplanes < d.M[2]) {
-            const int hz = p / 2, Mz = d.M[2];
-            int lo = d.zplane0 - hz, n = d.nzplanes + 2 * hz;
-            hipMemsetAsync(h->ge[0], 0, sizeof(double) * (size_t)d.M[0] * d.M[1] * Mz, st);
-            if (n >= Mz) ranges.push_back({0, 0, Mz});
-            else {
-                lo = ((lo % Mz) + Mz) % Mz;
-                const int first = std::min(n, Mz - lo);
-                ranges.push_back({0, lo, first});
-                if (n > first) ranges.push_back({0, 0, n - first});
-            }
-        } else {
-            ranges.push_back({l, 0, h->hp.Ml[l][2]});
-        }
-    }
-    // the large ones share one launch of the multi-level tiled kernel
     std::vector<bool> done(ranges.size(), false);
     if (!h->hp.literal && h->opt_conv_tiled >= 2) {
         ConvBatch B;
         B.n = 0;
         std::vector<size_t> members;
         for (size_t i = 0; i < ranges.size() && B.n < 8; i++) {
-            const Range &r = ranges[i];
+            const PlaneRange &r = ranges[i];
             const LevelStencil &S = h->hp.K[r.l];
             const int *M = h->hp.Ml[r.l];
             if (!(M[0] >= 16 && M[1] >= 8 && M[2] >= 8)) continue; // a short plane range of a large grid is fine
@@ -637,21 +625,89 @@ extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
     }
     for (size_t i = 0; i < ranges.size(); i++)
         if (!done[i]) convolve_level(h, ranges[i].l, h->gq[ranges[i].l], h->ge[ranges[i].l], ranges[i].z0, ranges[i].nz);
-    mark(h, T_TOP);
-    {
-        const int *ML = h->hp.Ml[L - 1];
-        const size_t nL = (size_t)ML[0] * ML[1] * ML[2];
-        if (h->hp.literal) {
-            // sL spans one full period on every axis (msmPeriodic.c:344-391), same index arithmetic as above
-            launch_conv_literal(st, h->gq[L - 1], h->dKL, ML, h->hp.KL.size, h->hp.KL.first, h->efour);
-            // the reference then overwrites elng with edir (msmPeriodic.c:1006-1011): nothing is added
-        } else {
-            conv_untiled(h, h->gq[L - 1], h->dKL, ML, h->hp.KL.size, h->hp.KL.first, h->efour, 0, ML[2]);
-            launch_axpy(st, h->ge[L - 1], h->efour, nL);
-        }
+}
+
+// Fourier (or, literal mode, full-period) top level on the coarsest grid
+static void top_level(msm_amd_handle *h) {
+    const int L = h->hp.d.L;
+    const int *ML = h->hp.Ml[L - 1];
+    const size_t nL = (size_t)ML[0] * ML[1] * ML[2];
+    if (h->hp.literal) {
+        // sL spans one full period on every axis (msmPeriodic.c:344-391), same index arithmetic as above
+        launch_conv_literal(h->stream, h->gq[L - 1], h->dKL, ML, h->hp.KL.size, h->hp.KL.first, h->efour);
+        // the reference then overwrites elng with edir (msmPeriodic.c:1006-1011): nothing is added
+    } else {
+        conv_untiled(h, h->gq[L - 1], h->dKL, ML, h->hp.KL.size, h->hp.KL.first, h->efour, 0, ML[2]);
+        launch_axpy(h->stream, h->ge[L - 1], h->efour, nL);
     }
-    mark(h, T_PRO);
-    for (int l = L - 2; l >= 0; l--) prolong_level_add(h, l, h->ge[l + 1], h->ge[l]);
+}
+
+extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
+    if (!h) return MSM_AMD_EINVAL;
+    const msm_amd_plan_desc &d = h->hp.d;
+    const int L = d.L, p = d.p;
+    hipStream_t st = h->stream;
+    // plane ranges to convolve on level 0: everything, except on a slab rank, where the potentials are needed on the
+    // owned planes plus p/2 planes either side (interpolation support) and the other planes of ge[0] are left at zero
+    std::vector<PlaneRange> fine, coarse;
+    if (d.nzplanes < d.M[2]) {
+        const int hz = p / 2, Mz = d.M[2];
+        int lo = d.zplane0 - hz, n = d.nzplanes + 2 * hz;
+        hipMemsetAsync(h->ge[0], 0, sizeof(double) * (size_t)d.M[0] * d.M[1] * Mz, st);
+        if (n >= Mz) fine.push_back({0, 0, Mz});
+        else {
+            lo = ((lo % Mz) + Mz) % Mz;
+            const int first = std::min(n, Mz - lo);
+            fine.push_back({0, lo, first});
+            if (n > first) fine.push_back({0, 0, n - first});
+        }
+    } else {
+        fine.push_back({0, 0, d.M[2]});
+    }
+    for (int l = 1; l < L; l++) coarse.push_back({l, 0, h->hp.Ml[l][2]});
+
+    // Two branches that only meet at the last prolongation: the level-0 convolution (most of the arithmetic, fills the
+    // chip) and everything on the coarser levels (a chain of small, latency-bound kernels: restrictions,
+    // convolutions of levels >= 1, top level, prolongations down to level 1).  On two streams the chain runs in the
+    // shadow of the large kernel; the arithmetic and its order are the same either way.
+    const bool two = h->opt_grid_streams && !h->hp.literal && L >= 2;
+    if (two && !h->stream_g) {
+        int prio_lo = 0, prio_hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIPCHK(hipStreamCreateWithPriority(&h->stream_g, hipStreamNonBlocking, prio_hi));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_gfork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_gjoin, hipEventDisableTiming));
+    }
+    mark(h, T_RES);
+    if (two) {
+        HIPCHK(hipEventRecord(h->ev_gfork, st));
+        HIPCHK(hipStreamWaitEvent(h->stream_g, h->ev_gfork, 0));
+        h->stream = h->stream_g; // the helpers below enqueue on the handle's stream
+    }
+    for (int l = 0; l + 1 < L; l++) restrict_level(h, l, h->gq[l], h->gq[l + 1]);
+    if (!two) {
+        mark(h, T_CONV);
+        std::vector<PlaneRange> all(fine);
+        all.insert(all.end(), coarse.begin(), coarse.end());
+        convolve_ranges(h, all); // one stream: the levels share a launch
+        mark(h, T_TOP);
+    } else {
+        convolve_ranges(h, coarse);
+    }
+    top_level(h);
+    if (!two) mark(h, T_PRO);
+    for (int l = L - 2; l >= 1; l--) prolong_level_add(h, l, h->ge[l + 1], h->ge[l]);
+    if (two) {
+        hipError_t e = hipEventRecord(h->ev_gjoin, h->stream_g);
+        h->stream = st;
+        if (e != hipSuccess) { set_error("hipEventRecord failed: %s", hipGetErrorString(e)); return MSM_AMD_EHIP; }
+        mark(h, T_CONV);
+        convolve_ranges(h, fine);
+        mark(h, T_TOP); // with two streams: what is left of the coarse branch once the level-0 convolution is done
+        HIPCHK(hipStreamWaitEvent(st, h->ev_gjoin, 0));
+        mark(h, T_PRO);
+    }
+    if (L >= 2) prolong_level_add(h, 0, h->ge[1], h->ge[0]);
     HIPCHK(hipGetLastError());
     return MSM_AMD_OK;
 }

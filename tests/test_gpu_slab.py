@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _worker(rank, world, port, N, p, L, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)   # a stuck rank ends with its stacks instead of hanging the run
     import torch
     import torch.distributed as dist
     import msm_amd
