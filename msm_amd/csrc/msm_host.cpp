@@ -211,12 +211,15 @@ static void build_level(HostPlan &hp, int l) {
         R[d] = (int)std::ceil((jm * hp.hl[l][d] + rcut) / hp.d.A[d]);
         if (hp.literal) R[d] = 5; // the reference sums images -5..5 whatever the cell (msmPeriodic.c:536-538)
     }
-    std::vector<double> G((size_t)ext[0] * ext[1] * ext[2]);
-    for (int jz = 0; jz < ext[2]; jz++)
-        for (int jy = 0; jy < ext[1]; jy++)
-            for (int jx = 0; jx < ext[0]; jx++) {
-                const double x = (S.first[0] - W + jx) * hp.hl[l][0], y = (S.first[1] - W + jy) * hp.hl[l][1],
-                             z = (S.first[2] - W + jz) * hp.hl[l][2];
+    // The image sum is even in every coordinate (the images come in +- pairs), so it is evaluated once per
+    // (|nx|, |ny|, |nz|) and copied to the other octants: an eighth of the kernel evaluations.
+    int amax[3];
+    for (int d = 0; d < 3; d++) amax[d] = std::max(std::abs(S.first[d] - W), std::abs(S.first[d] - W + ext[d] - 1));
+    std::vector<double> T((size_t)(amax[0] + 1) * (amax[1] + 1) * (amax[2] + 1));
+    for (int jz = 0; jz <= amax[2]; jz++)
+        for (int jy = 0; jy <= amax[1]; jy++)
+            for (int jx = 0; jx <= amax[0]; jx++) {
+                const double x = jx * hp.hl[l][0], y = jy * hp.hl[l][1], z = jz * hp.hl[l][2];
                 double g = 0.0;
                 for (int pz = -R[2]; pz <= R[2]; pz++) {
                     const double dz = z - hp.d.A[2] * pz;
@@ -232,7 +235,14 @@ static void build_level(HostPlan &hp, int l) {
                         }
                     }
                 }
-                G[((size_t)jz * ext[1] + jy) * ext[0] + jx] = g;
+                T[((size_t)jz * (amax[1] + 1) + jy) * (amax[0] + 1) + jx] = g;
+            }
+    std::vector<double> G((size_t)ext[0] * ext[1] * ext[2]);
+    for (int jz = 0; jz < ext[2]; jz++)
+        for (int jy = 0; jy < ext[1]; jy++)
+            for (int jx = 0; jx < ext[0]; jx++) {
+                const int ax = std::abs(S.first[0] - W + jx), ay = std::abs(S.first[1] - W + jy), az = std::abs(S.first[2] - W + jz);
+                G[((size_t)jz * ext[1] + jy) * ext[0] + jx] = T[((size_t)az * (amax[1] + 1) + ay) * (amax[0] + 1) + ax];
             }
     const std::vector<double> &w = hp.wprime;
     // x pass
@@ -299,25 +309,33 @@ static void build_top(HostPlan &hp) {
                 F[off] = x * c * c;
             }
     typedef std::complex<double> cd;
-    auto phase = [](int k, int n, int M) {
-        long t = ((long)k * n) % M;
-        if (t < 0) t += M;
-        const double th = 2 * PI * (double)t / (double)M;
-        return cd(std::cos(th), std::sin(th));
+    // e^{2 pi i t / M} for t in [0, M), per axis: k n is reduced mod M first, so every phase is one of these
+    std::vector<cd> roots[3];
+    for (int d = 0; d < 3; d++) {
+        roots[d].resize(ML[d]);
+        for (int t = 0; t < ML[d]; t++) {
+            const double th = 2 * PI * (double)t / (double)ML[d];
+            roots[d][t] = cd(std::cos(th), std::sin(th));
+        }
+    }
+    auto phase = [&](int k, int n, int d) {
+        long t = ((long)k * n) % ML[d];
+        if (t < 0) t += ML[d];
+        return roots[d][t];
     };
     std::vector<cd> S1((size_t)cn * cn * ML[0]), S2((size_t)cn * ML[1] * ML[0]);
     for (int kz = 0; kz < cn; kz++)
         for (int ky = 0; ky < cn; ky++)
             for (int nx = 0; nx < ML[0]; nx++) {
                 cd s = 0.0;
-                for (int kx = 0; kx < cn; kx++) s += F[((size_t)kz * cn + ky) * cn + kx] * phase(kx - kmax, nx, ML[0]);
+                for (int kx = 0; kx < cn; kx++) s += F[((size_t)kz * cn + ky) * cn + kx] * phase(kx - kmax, nx, 0);
                 S1[((size_t)kz * cn + ky) * ML[0] + nx] = s;
             }
     for (int kz = 0; kz < cn; kz++)
         for (int ny = 0; ny < ML[1]; ny++)
             for (int nx = 0; nx < ML[0]; nx++) {
                 cd s = 0.0;
-                for (int ky = 0; ky < cn; ky++) s += S1[((size_t)kz * cn + ky) * ML[0] + nx] * phase(ky - kmax, ny, ML[1]);
+                for (int ky = 0; ky < cn; ky++) s += S1[((size_t)kz * cn + ky) * ML[0] + nx] * phase(ky - kmax, ny, 1);
                 S2[((size_t)kz * ML[1] + ny) * ML[0] + nx] = s;
             }
     hp.KL.v.assign((size_t)ML[0] * ML[1] * ML[2], 0.0);
@@ -329,7 +347,7 @@ static void build_top(HostPlan &hp) {
         for (int ny = 0; ny < ML[1]; ny++)
             for (int nx = 0; nx < ML[0]; nx++) {
                 cd s = 0.0;
-                for (int kz = 0; kz < cn; kz++) s += S2[((size_t)kz * ML[1] + ny) * ML[0] + nx] * phase(kz - kmax, nz, ML[2]);
+                for (int kz = 0; kz < cn; kz++) s += S2[((size_t)kz * ML[1] + ny) * ML[0] + nx] * phase(kz - kmax, nz, 2);
                 hp.KL.v[((size_t)nz * ML[1] + ny) * ML[0] + nx] = s.real();
             }
 }
