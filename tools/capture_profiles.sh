@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round profile capture on the GPU box: bench line, rocprofv3 kernel stats of the same command, PMC passes.
+# Profile capture on the GPU box: bench line, rocprofv3 kernel stats of the same command, PMC passes.
 # Every step has its own time limit; the script stops at the first failure.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/final

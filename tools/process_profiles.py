@@ -1,4 +1,4 @@
-"""Turn what tools/capture_profiles.sh left under gpurun_out/final/ into the round's files under profiles/.
+"""Turn what tools/capture_profiles.sh left under gpurun_out/final/ into files under profiles/ with the given name prefix.
 
     python tools/process_profiles.py r01
 """
