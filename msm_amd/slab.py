@@ -136,3 +136,38 @@ class SlabRank:
 
     def owned_acc(self):
         return self.acc[:self.n_own]
+
+
+def direct_rows(world, rank, N):
+    """Rows [i0, i1) of the open-boundary direct sum that `rank` computes: equal shares, the remainder to the first ranks."""
+    base, rem = divmod(N, world)
+    i0 = rank * base + min(rank, rem)
+    return i0, i0 + base + (1 if rank < rem else 0)
+
+
+def direct_sharded(torch, dist, r_all, q_all, rank, world, local_rank=0, host_staged=None):
+    """Open-boundary direct sum (direct() of msm/msmLibrary.h:212, loop of msm/nonperiodic.c:12-22) over the GPUs of a node.
+
+    Every rank holds all positions and computes the rows [i0, i1) of the pair matrix (msm_amd_direct_device); the
+    path has no exchange step: the slice energies are added with one all-reduce of a scalar, and each rank
+    keeps the accelerations of its own rows.  Returns (u_total, acc_rows (i1 - i0, 3) CUDA tensor, (i0, i1))."""
+    import ctypes as C
+    lib = capi.load()
+    dev = torch.device("cuda:%d" % local_rank)
+    rd = torch.as_tensor(np.ascontiguousarray(r_all, dtype=np.float64), device=dev)
+    qd = torch.as_tensor(np.ascontiguousarray(q_all, dtype=np.float64), device=dev)
+    N = qd.shape[0]
+    i0, i1 = direct_rows(world, rank, N)
+    acc = torch.empty((max(i1 - i0, 1), 3), dtype=torch.float64, device=dev)
+    work = torch.empty(lib.msm_amd_direct_work_doubles(N), dtype=torch.float64, device=dev)
+    u = C.c_double(0.0)
+    if i1 > i0:
+        with torch.cuda.device(dev):
+            capi.check(lib.msm_amd_direct_device(N, rd.data_ptr(), qd.data_ptr(), i0, i1, capi.ACC_GRADIENT, acc.data_ptr(),
+                                                 work.data_ptr(), torch.cuda.current_stream().cuda_stream, C.byref(u)),
+                       "direct_device")
+    if host_staged is None:
+        host_staged = dist.get_backend() != "nccl"
+    t = torch.tensor([u.value], dtype=torch.float64, device="cpu" if host_staged else dev)
+    dist.all_reduce(t)
+    return float(t.item()), acc[:i1 - i0], (i0, i1)

@@ -61,3 +61,39 @@ def test_slab_ranks_match_single_gpu(tmp_path, world, N, p, L):
     assert (seen == 1).all()
     err = np.sqrt(((acc - acc1) ** 2).sum() / (acc1 ** 2).sum())
     assert err < 1e-12, err
+
+
+def _direct_worker(rank, world, port, N, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)
+    import torch
+    import torch.distributed as dist
+    from msm_amd.slab import direct_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=47)
+    u, acc, (i0, i1) = direct_sharded(torch, dist, r, q, rank, world)
+    np.savez(os.path.join(out_dir, "direct%d.npz" % rank), u=u, i0=i0, i1=i1, acc=acc.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_direct_sum_rows_over_ranks(tmp_path):
+    """The non-periodic direct sum with the rows of the pair matrix split over 3 ranks (sharing cuda:0): the slice
+    energies add up to the one-GPU energy and the rows are the one-GPU rows, bit for bit (same kernel, same order)."""
+    import torch.multiprocessing as mp
+    import msm_amd
+    N, world = 5001, 3
+    mp.spawn(_direct_worker, args=(world, _free_port(), N, str(tmp_path)), nprocs=world, join=True)
+    r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=47)
+    u1, acc1 = msm_amd.direct(r, q)
+    uo, ao = O.direct(r, q, nthreads=8)
+    assert abs(u1 - uo) < 1e-12 * abs(uo)
+    rows = 0
+    for k in range(world):
+        z = np.load(os.path.join(str(tmp_path), "direct%d.npz" % k))
+        assert abs(float(z["u"]) - u1) < 1e-12 * abs(u1)
+        assert np.array_equal(z["acc"], acc1[int(z["i0"]):int(z["i1"])])
+        rows += int(z["i1"]) - int(z["i0"])
+    assert rows == N

@@ -156,3 +156,14 @@ def test_slab_reassembles_single_rank_result(tmp_path, world, p, L):
     assert (seen == 1).all()
     err = np.sqrt(((acc - ref["acc"]) ** 2).sum() / (ref["acc"] ** 2).sum())
     assert err < 1e-12, err
+
+
+def test_direct_rows_partition():
+    from msm_amd.slab import direct_rows
+    for N in (1, 7, 1000, 1000003):
+        for world in (1, 2, 3, 8):
+            cuts = [direct_rows(world, k, N) for k in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == N
+            assert all(cuts[k][1] == cuts[k + 1][0] for k in range(world - 1))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
