@@ -81,7 +81,7 @@ class SlabRank:
             g.manual_seed(7 + rank)
             self.delta = (torch.rand(self.r.shape, generator=g, dtype=torch.float64, device=dev) - 0.5) * margin
             self.sign = 1.0
-        self.last_energies = None
+        self._pending = self._energies = None
 
     def _host_staged(self):
         # a gloo group cannot move device memory: stage through the host (functional testing on one GPU)
@@ -101,8 +101,11 @@ class SlabRank:
             parts = [self.q0[k * self.nz:(k + 1) * self.nz] for k in range(self.world)]
             return self.dist.all_gather(parts, self.send, async_op=async_op)
 
-    def step(self, marks=None):
-        """One evaluation.  marks: optional callable(name) invoked between stages (bench.py records events)."""
+    def step(self, marks=None, want_energies=True):
+        """One evaluation.  marks: optional callable(name) invoked between stages (bench.py records events).
+
+        With want_energies=False nothing waits for the GPU: the reduced sums stay on the device and `last_energies`
+        combines them when it is read, so a time-stepping loop queues its evaluations back to back."""
         eng = self.eng
         mark = marks if marks is not None else (lambda name: None)
         if self.perturb:
@@ -131,8 +134,14 @@ class SlabRank:
         if self._host_staged():
             s = s.cpu()
         self.dist.all_reduce(s)
-        self.last_energies = eng.combine_energies(s.cpu().numpy())
-        return self.last_energies
+        self._pending, self._energies = s, None
+        return self.last_energies if want_energies else None
+
+    @property
+    def last_energies(self):
+        if self._energies is None and self._pending is not None:
+            self._energies = self.eng.combine_energies(self._pending.cpu().numpy())
+        return self._energies
 
     def owned_acc(self):
         return self.acc[:self.n_own]

@@ -19,10 +19,10 @@ W = int(sys.argv[1])
 r, q = make_system(N, 20261113)
 desc = msm_amd.plan_auto(N, (1.0, 1.0, 1.0), p, 10, 4.0, 0)
 s = SlabRank(torch, FakeDist(), msm_amd, desc, r, q, W // 2, W, 0)
-for _ in range(3): s.step()
+for _ in range(3): s.step(want_energies=False)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(20): s.step()
+for _ in range(20): s.step(want_energies=False)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 20
 prof = SlabProfiler(torch, s).profile(5)
