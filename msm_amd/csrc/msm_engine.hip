@@ -47,6 +47,8 @@ struct msm_amd_handle {
     std::vector<double *> dKsub;
     std::vector<int> sub_s, sub_n;
     double *efour = nullptr, *dKL = nullptr, *tmpA = nullptr, *tmpB = nullptr;
+    double *dTsum = nullptr, *dTfour = nullptr; // coarsest-level + Fourier stencils as offset tables (both span one period)
+    int opt_top_fused = 1;
     // reductions
     double *epart = nullptr;
     int nepart = 0;
@@ -339,6 +341,26 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
     {
         const size_t nL = h->hp.KL.v.size(), n0 = (size_t)d.M[0] * d.M[1] * d.M[2];
         DA(h->efour, nL); DA(h->dKL, nL);
+        {
+            const LevelStencil &S = h->hp.K[L - 1];
+            const int *ML = h->hp.Ml[L - 1];
+            if (!literal && S.size[0] == ML[0] && S.size[1] == ML[1] && S.size[2] == ML[2] && h->hp.KL.v.size() == nL) {
+                // e[m] = sum_s K[s] q[m - (first + s)]: the tap at offset o = (first + s) mod M
+                std::vector<double> ts(nL), tf(nL);
+                for (int oz = 0; oz < ML[2]; oz++)
+                    for (int oy = 0; oy < ML[1]; oy++)
+                        for (int ox = 0; ox < ML[0]; ox++) {
+                            const int sx = ((ox - S.first[0]) % ML[0] + ML[0]) % ML[0], sy = ((oy - S.first[1]) % ML[1] + ML[1]) % ML[1],
+                                      sz = ((oz - S.first[2]) % ML[2] + ML[2]) % ML[2];
+                            const size_t o = ((size_t)oz * ML[1] + oy) * ML[0] + ox;
+                            tf[o] = h->hp.KL.v[o]; // KL starts at offset 0
+                            ts[o] = S.v[((size_t)sz * S.size[1] + sy) * S.size[0] + sx] + tf[o];
+                        }
+                DA(h->dTsum, nL); DA(h->dTfour, nL);
+                HIPCHK(hipMemcpy(h->dTsum, ts.data(), nL * sizeof(double), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(h->dTfour, tf.data(), nL * sizeof(double), hipMemcpyHostToDevice));
+            }
+        }
         HIPCHK(hipMemset(h->efour, 0, nL * sizeof(double)));
         HIPCHK(hipMemcpy(h->dKL, h->hp.KL.v.data(), nL * sizeof(double), hipMemcpyHostToDevice));
         DA(h->tmpA, n0 / 2 + 1); DA(h->tmpB, n0 / 4 + 1);
@@ -387,7 +409,7 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     for (auto p : h->dK) hipFree(p);
     for (auto p : h->dKt) hipFree(p);
     for (auto p : h->dKsub) hipFree(p);
-    hipFree(h->efour); hipFree(h->dKL); hipFree(h->tmpA); hipFree(h->tmpB); hipFree(h->epart); hipFree(h->parts);
+    hipFree(h->efour); hipFree(h->dKL); hipFree(h->dTsum); hipFree(h->dTfour); hipFree(h->tmpA); hipFree(h->tmpB); hipFree(h->epart); hipFree(h->parts);
     hipFree(h->d_energies);
     if (h->h_energies) hipHostFree(h->h_energies);
     hipFree(h->s_r); hipFree(h->s_q); hipFree(h->s_acc);
@@ -441,6 +463,7 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "anterp_cols_order4")) { anterp_cols_order4 = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "anterp_cols")) { anterp_cols_enabled = value != 0; return MSM_AMD_OK; } // process-wide A/B switch
     if (!strcmp(key, "overlap")) { h->opt_overlap = value; return MSM_AMD_OK; }
+    if (!strcmp(key, "top_fused")) { h->opt_top_fused = value; return MSM_AMD_OK; }
     if (!strcmp(key, "grid_streams")) { h->opt_grid_streams = value; return MSM_AMD_OK; }
     if (!strcmp(key, "transfer_fused")) { h->opt_transfer_fused = value; return MSM_AMD_OK; }
     if (!strcmp(key, "transfer_fused_max")) { h->opt_transfer_fused_max = value; return MSM_AMD_OK; }
@@ -627,12 +650,21 @@ static void convolve_ranges(msm_amd_handle *h, const std::vector<PlaneRange> &ra
         if (!done[i]) convolve_level(h, ranges[i].l, h->gq[ranges[i].l], h->ge[ranges[i].l], ranges[i].z0, ranges[i].nz);
 }
 
+static bool top_fused(const msm_amd_handle *h) {
+    const msm_amd_plan_desc &d = h->hp.d;
+    // (a slab rank of a one-level plan convolves only some planes of level 0 = the coarsest level: not fused)
+    return h->opt_top_fused && h->dTsum && (d.L > 1 || d.nzplanes >= d.M[2]);
+}
+
 // Fourier (or, literal mode, full-period) top level on the coarsest grid
 static void top_level(msm_amd_handle *h) {
     const int L = h->hp.d.L;
     const int *ML = h->hp.Ml[L - 1];
     const size_t nL = (size_t)ML[0] * ML[1] * ML[2];
-    if (h->hp.literal) {
+    if (top_fused(h)) {
+        // the coarsest level's own convolution was left out of the coarse ranges: both in one pass
+        launch_conv_small_pair(h->stream, h->gq[L - 1], h->dTsum, h->dTfour, ML, h->ge[L - 1], h->efour);
+    } else if (h->hp.literal) {
         // sL spans one full period on every axis (msmPeriodic.c:344-391), same index arithmetic as above
         launch_conv_literal(h->stream, h->gq[L - 1], h->dKL, ML, h->hp.KL.size, h->hp.KL.first, h->efour);
         // the reference then overwrites elng with edir (msmPeriodic.c:1006-1011): nothing is added
@@ -664,7 +696,10 @@ extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
     } else {
         fine.push_back({0, 0, d.M[2]});
     }
-    for (int l = 1; l < L; l++) coarse.push_back({l, 0, h->hp.Ml[l][2]});
+    const bool fused_top = top_fused(h);
+    for (int l = 1; l < L; l++)
+        if (!(fused_top && l == L - 1)) coarse.push_back({l, 0, h->hp.Ml[l][2]});
+    if (fused_top && L == 1) fine.clear();
 
     // Two branches that only meet at the last prolongation: the level-0 convolution (most of the arithmetic, fills the
     // chip) and everything on the coarser levels (a chain of small, latency-bound kernels: restrictions,

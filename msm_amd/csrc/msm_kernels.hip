@@ -1032,6 +1032,47 @@ __global__ __launch_bounds__(256) void k_conv_small(const double *__restrict__ q
     }
 }
 
+// The coarsest grid level and the Fourier level in one pass.  Both stencils span exactly one period there, so
+// each is a table over the offset (m - n) mod M; Ta holds their sum, Tb the Fourier part alone (its product with
+// the charges is an energy term of its own):  ea[m] = sum_n Ta[m - n] q[n],  eb[m] = sum_n Tb[m - n] q[n].
+__global__ __launch_bounds__(256) void k_conv_small_pair(const double *__restrict__ q, const double *__restrict__ Ta,
+                                                         const double *__restrict__ Tb, double *__restrict__ ea,
+                                                         double *__restrict__ eb, int Mx, int My, int Mz) {
+    // one workgroup per output node (a few thousand of them, a few thousand taps each): the kernel is over when the
+    // slowest node is, so the taps of a node are spread over 256 lanes rather than 64
+    __shared__ double red[2][4];
+    const int nn = Mx * My * Mz;
+    const int w = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mx = w % Mx, my = (w / Mx) % My, mz = w / (Mx * My);
+    double sa = 0.0, sb = 0.0;
+    for (int t = threadIdx.x; t < nn; t += 256) {
+        const int nx = t % Mx, ny = (t / Mx) % My, nz = t / (Mx * My);
+        int ox = mx - nx, oy = my - ny, oz = mz - nz; // each in (-M, M)
+        ox += ox < 0 ? Mx : 0; oy += oy < 0 ? My : 0; oz += oz < 0 ? Mz : 0;
+        const int o = (oz * My + oy) * Mx + ox;
+        const double v = q[t];
+        sa = fma(Ta[o], v, sa);
+        sb = fma(Tb[o], v, sb);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sa += __shfl_xor(sa, off);
+        sb += __shfl_xor(sb, off);
+    }
+    if (lane == 0) { red[0][wave] = sa; red[1][wave] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ea[w] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        eb[w] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+void launch_conv_small_pair(hipStream_t st, const double *q, const double *Ta, const double *Tb, const int M[3], double *ea,
+                            double *eb) {
+    const int nn = M[0] * M[1] * M[2];
+    hipLaunchKernelGGL(k_conv_small_pair, dim3(nn), dim3(256), 0, st, q, Ta, Tb, ea, eb, M[0], M[1], M[2]);
+}
+
 void launch_conv_small(hipStream_t st, const double *q, const double *K, const int M[3], const int ksize[3],
                        const int kfirst[3], double *e, int z0, int nz, int accumulate) {
     ConvArgs c;

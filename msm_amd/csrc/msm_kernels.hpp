@@ -157,6 +157,9 @@ struct ConvBatch {
     double *e[8];
 };
 bool launch_conv_multi(hipStream_t st, ConvBatch &B);
+// coarsest level + Fourier level, both full-period, as offset tables Ta (sum) and Tb (Fourier part): ea = Ta * q, eb = Tb * q
+void launch_conv_small_pair(hipStream_t st, const double *q, const double *Ta, const double *Tb, const int M[3], double *ea,
+                            double *eb);
 // ---- grid convolution: e[m] = sum_s K[s] q[(m - (first + s)) mod M] for planes [z0, z0+nz) ----
 void launch_conv_direct(hipStream_t st, const double *q, const double *K, const int M[3], const int ksize[3],
                         const int kfirst[3], double *e, int z0, int nz, int accumulate);
