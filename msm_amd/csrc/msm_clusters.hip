@@ -52,6 +52,40 @@ __global__ void k_cl_colcount(const int *__restrict__ start, ClusterGeom g, int 
     colncl[col] = (n + CL_G - 1) / CL_G;
 }
 
+// Clusters per column and their exclusive prefix sums (clstart[ncols] = number of clusters) by one workgroup: a
+// few thousand columns, so one launch instead of a counting kernel and a three-kernel scan.
+__global__ __launch_bounds__(1024) void k_cl_colscan(const int *__restrict__ start, ClusterGeom g, int *__restrict__ colncl,
+                                                     int *__restrict__ clstart) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < g.ncols; base += 1024) {
+        const int col = base + threadIdx.x;
+        int v = 0;
+        if (col < g.ncols) {
+            v = (start[(col + 1) * g.nzf] - start[col * g.nzf] + CL_G - 1) / CL_G;
+            colncl[col] = v;
+        }
+        int incl = v; // inclusive scan inside the wave, then over the 16 wave totals
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wave; w++) before += wsum[w];
+        if (col < g.ncols) clstart[col] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) clstart[g.ncols] = carry;
+}
+
 // Slot of a particle: its column's first slot + its rank inside the column (fine bins in z order, original
 // index inside a fine bin, so the layout does not depend on the order the atomics of the scatter arrived in).
 __global__ void k_cl_finalize(const double *__restrict__ r, const double *__restrict__ q, int N, ClusterGeom g,
@@ -115,8 +149,12 @@ void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, i
     const int tb = 256, gb = (N + tb - 1) / tb;
     hipLaunchKernelGGL(k_cl_count, dim3(gb), dim3(tb), 0, st, d_r, N, g, bin_of, b.count, arrival);
     launch_exclusive_scan(st, b.count, g.nbins, scan_tmp, b.start);
-    hipLaunchKernelGGL(k_cl_colcount, dim3((g.ncols + tb - 1) / tb), dim3(tb), 0, st, b.start, g, b.colncl);
-    launch_exclusive_scan(st, b.colncl, g.ncols, scan_tmp, b.clstart);
+    if (g.ncols <= (1 << 18)) {
+        hipLaunchKernelGGL(k_cl_colscan, dim3(1), dim3(1024), 0, st, b.start, g, b.colncl, b.clstart);
+    } else {
+        hipLaunchKernelGGL(k_cl_colcount, dim3((g.ncols + tb - 1) / tb), dim3(tb), 0, st, b.start, g, b.colncl);
+        launch_exclusive_scan(st, b.colncl, g.ncols, scan_tmp, b.clstart);
+    }
     launch_bin_scatter(st, bin_of, arrival, N, b.start, slot_idx);
     hipLaunchKernelGGL(k_cl_finalize, dim3(gb), dim3(tb), 0, st, d_r, d_q, N, g, bin_of, b.start, b.clstart, slot_idx, b.order,
                        b.ps);

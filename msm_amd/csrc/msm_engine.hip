@@ -767,15 +767,18 @@ static int queue_energies(msm_amd_handle *h, bool raw = false) {
     const size_t plane = (size_t)d.M[0] * d.M[1];
     const size_t nL = (size_t)h->hp.Ml[L - 1][0] * h->hp.Ml[L - 1][1] * h->hp.Ml[L - 1][2];
     double *pg = h->parts, *pf = h->parts + NPARTS, *pc = h->parts + 2 * NPARTS;
-    launch_dot_partials(h->stream, h->gq[0] + plane * d.zplane0, h->ge[0] + plane * d.zplane0, plane * d.nzplanes, pg, NPARTS);
-    launch_dot_partials(h->stream, h->gq[L - 1], h->efour, nL, pf, NPARTS);
-    launch_charge_partials(h->stream, h->cur_q, (size_t)h->n_owned, pc, NPARTS);
+    EnergyPartialsArgs pa;
+    pa.g_q = h->gq[0] + plane * d.zplane0; pa.g_e = h->ge[0] + plane * d.zplane0; pa.g_n = plane * d.nzplanes; pa.g_parts = pg;
+    pa.f_q = h->gq[L - 1]; pa.f_e = h->efour; pa.f_n = nL; pa.f_parts = pf;
+    pa.c_q = h->cur_q; pa.c_n = (size_t)h->n_owned; pa.c_parts = pc;
+    pa.p_in = h->epart; pa.p_n = h->nepart; pa.p_parts = nullptr;
     EnergyInputs in;
     in.pair_parts = h->epart; in.n_pair = h->nepart;
     if (h->nepart > 8 * NPARTS) { // one block sums these lists: shorten a long one first
-        launch_sum_partials(h->stream, h->epart, h->nepart, h->parts + 4 * NPARTS, NPARTS);
+        pa.p_parts = h->parts + 4 * NPARTS;
         in.pair_parts = h->parts + 4 * NPARTS; in.n_pair = NPARTS;
     }
+    launch_energy_partials(h->stream, pa, NPARTS);
     in.grid_parts = pg; in.n_grid = NPARTS;
     in.four_parts = pf; in.n_four = NPARTS;
     in.charge_parts = pc; in.n_charge = NPARTS;

@@ -1459,6 +1459,48 @@ __device__ double sum_array(const double *__restrict__ p, int n, double *red) {
     return t;
 }
 
+// The four partial reductions of an evaluation in one launch (each a few microseconds of work, and every launch in
+// the chain costs about as much again): blockIdx.y picks the reduction, blockIdx.x the part; the sums are formed
+// exactly as by k_dot_partials, k_charge_partials and k_sum_partials with gridDim.x parts.
+__global__ __launch_bounds__(256) void k_energy_partials(EnergyPartialsArgs a) {
+    __shared__ double red[256];
+    const int part = blockIdx.x, np = gridDim.x;
+    if (blockIdx.y <= 1) {
+        const double *__restrict__ x = blockIdx.y == 0 ? a.g_q : a.f_q;
+        const double *__restrict__ y = blockIdx.y == 0 ? a.g_e : a.f_e;
+        const size_t n = blockIdx.y == 0 ? a.g_n : a.f_n;
+        double s = 0.0;
+        for (size_t i = (size_t)part * 256 + threadIdx.x; i < n; i += (size_t)np * 256) s = fma(x[i], y[i], s);
+        const double t = block_sum<256>(s, red);
+        if (threadIdx.x == 0) (blockIdx.y == 0 ? a.g_parts : a.f_parts)[part] = t;
+    } else if (blockIdx.y == 2) {
+        double s = 0.0, s2 = 0.0;
+        for (size_t i = (size_t)part * 256 + threadIdx.x; i < a.c_n; i += (size_t)np * 256) {
+            const double v = a.c_q[i];
+            s += v;
+            s2 = fma(v, v, s2);
+        }
+        const double t = block_sum<256>(s, red);
+        __syncthreads();
+        const double t2 = block_sum<256>(s2, red);
+        if (threadIdx.x == 0) {
+            a.c_parts[part] = t;
+            a.c_parts[np + part] = t2;
+        }
+    } else {
+        if (!a.p_parts) return; // a short list of pair partials is summed by the finishing kernel itself
+        const int per = (a.p_n + np - 1) / np;
+        const int lo = part * per, hi = min(a.p_n, lo + per);
+        double s = 0.0;
+        for (int i = lo + threadIdx.x; i < hi; i += 256) s += a.p_in[i];
+        const double t = block_sum<256>(s, red);
+        if (threadIdx.x == 0) a.p_parts[part] = t;
+    }
+}
+void launch_energy_partials(hipStream_t st, const EnergyPartialsArgs &a, int nparts) {
+    hipLaunchKernelGGL(k_energy_partials, dim3(nparts, 4), dim3(256), 0, st, a);
+}
+
 // (A)..(F) and the total (msmPeriodic.c:1305-1359; msmSimple.c:1968-1969)
 __global__ __launch_bounds__(256) void k_finalize_energies(EnergyInputs in, double *__restrict__ out) {
     __shared__ double red[256];

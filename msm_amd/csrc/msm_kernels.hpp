@@ -187,6 +187,15 @@ struct EnergyInputs {
     double self_image_sum, csr, gamma0_over_a;
     int literal;                                // sign / bookkeeping of msmPeriodic.c:1002,1334-1359
 };
+// the partial sums of an evaluation in one launch: q0.e0 (g_*), qL.efour (f_*), sum q and sum q^2 (c_*, parts and
+// parts + nparts), pair partials (p_*, skipped when p_parts is null)
+struct EnergyPartialsArgs {
+    const double *g_q, *g_e; size_t g_n; double *g_parts;
+    const double *f_q, *f_e; size_t f_n; double *f_parts;
+    const double *c_q; size_t c_n; double *c_parts;
+    const double *p_in; int p_n; double *p_parts;
+};
+void launch_energy_partials(hipStream_t st, const EnergyPartialsArgs &a, int nparts);
 void launch_finalize_energies(hipStream_t st, const EnergyInputs &in, double *out7);
 // raw sums for a slab rank: out5 = [pair sum, q0.e0 over owned planes, qL.efour, sum q, sum q^2]
 void launch_raw_sums(hipStream_t st, const EnergyInputs &in, double *out5);
