@@ -832,36 +832,46 @@ struct AxisArgs {
 };
 
 // out[.., m, ..] = sum_{|j| <= h} J_|j| in[.., (2m + j) mod Min, ..]
+// (index arithmetic in 32 bits and wraps by one conditional add: these kernels do little else)
+__device__ __forceinline__ int wrap_near(int v, int M) { return v < 0 ? v + M : (v >= M ? v - M : v); } // v in [-M, 2M)
 __global__ __launch_bounds__(256) void k_restrict_axis(const double *__restrict__ in, double *__restrict__ out, AxisArgs a) {
-    const size_t n = (size_t)a.Mout[0] * a.Mout[1] * a.Mout[2];
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned n = (unsigned)a.Mout[0] * a.Mout[1] * a.Mout[2];
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    int c[3] = {(int)(idx % a.Mout[0]), (int)((idx / a.Mout[0]) % a.Mout[1]), (int)(idx / ((size_t)a.Mout[0] * a.Mout[1]))};
+    const unsigned row = idx / (unsigned)a.Mout[0];
+    int c[3] = {(int)(idx - row * a.Mout[0]), (int)(row % (unsigned)a.Mout[1]), (int)(row / (unsigned)a.Mout[1])};
     const int m = c[a.axis], Ma = a.Min[a.axis];
-    const size_t stride = a.axis == 0 ? 1 : (a.axis == 1 ? (size_t)a.Min[0] : (size_t)a.Min[0] * a.Min[1]);
+    const int stride = a.axis == 0 ? 1 : (a.axis == 1 ? a.Min[0] : a.Min[0] * a.Min[1]);
     c[a.axis] = 0;
     const double *base = in + ((size_t)c[2] * a.Min[1] + c[1]) * a.Min[0] + c[0];
     double s = 0.0;
-    for (int j = -a.h; j <= a.h; j++) s = fma(a.J[j < 0 ? -j : j], base[(size_t)modp(2 * m + j, Ma) * stride], s);
+    if (Ma >= a.h) {
+        for (int j = -a.h; j <= a.h; j++) s = fma(a.J[j < 0 ? -j : j], base[(size_t)wrap_near(2 * m + j, Ma) * stride], s);
+    } else {
+        for (int j = -a.h; j <= a.h; j++) s = fma(a.J[j < 0 ? -j : j], base[(size_t)modp(2 * m + j, Ma) * stride], s);
+    }
     out[idx] = s;
 }
 
 // out[.., n, ..] (+)= sum_{|j| <= h, n-j even} J_|j| in[.., ((n-j)/2) mod Min, ..]
 __global__ __launch_bounds__(256) void k_prolong_axis(const double *__restrict__ in, double *__restrict__ out, AxisArgs a,
                                                       int accumulate) {
-    const size_t n = (size_t)a.Mout[0] * a.Mout[1] * a.Mout[2];
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned n = (unsigned)a.Mout[0] * a.Mout[1] * a.Mout[2];
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    int c[3] = {(int)(idx % a.Mout[0]), (int)((idx / a.Mout[0]) % a.Mout[1]), (int)(idx / ((size_t)a.Mout[0] * a.Mout[1]))};
+    const unsigned row = idx / (unsigned)a.Mout[0];
+    int c[3] = {(int)(idx - row * a.Mout[0]), (int)(row % (unsigned)a.Mout[1]), (int)(row / (unsigned)a.Mout[1])};
     const int nn = c[a.axis], Ma = a.Min[a.axis];
-    const size_t stride = a.axis == 0 ? 1 : (a.axis == 1 ? (size_t)a.Min[0] : (size_t)a.Min[0] * a.Min[1]);
+    const int stride = a.axis == 0 ? 1 : (a.axis == 1 ? a.Min[0] : a.Min[0] * a.Min[1]);
     c[a.axis] = 0;
     const double *base = in + ((size_t)c[2] * a.Min[1] + c[1]) * a.Min[0] + c[0];
     double s = 0.0;
+    const bool near = Ma >= a.h; // (nn - j) / 2 then lies in [-Ma, 2 Ma)
     for (int j = -a.h; j <= a.h; j++) {
         const int t = nn - j;
         if (t & 1) continue;
-        s = fma(a.J[j < 0 ? -j : j], base[(size_t)modp(t / 2, Ma) * stride], s);
+        const int src = near ? wrap_near(t / 2, Ma) : modp(t / 2, Ma);
+        s = fma(a.J[j < 0 ? -j : j], base[(size_t)src * stride], s);
     }
     out[idx] = accumulate ? out[idx] + s : s;
 }
