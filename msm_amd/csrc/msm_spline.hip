@@ -298,10 +298,11 @@ __global__ __launch_bounds__(256) void k_anterp_combine(const double *__restrict
                                                         SplineParams sp, TileGeom tl, double *__restrict__ grid) {
     constexpr int R = AT + P - 1, R3 = R * R * R;
     const int Mx = sp.M[0], My = sp.M[1];
-    const size_t nplane = (size_t)Mx * My;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned nplane = (unsigned)Mx * My;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; // 32-bit index arithmetic: a level-0 grid has < 2^32 nodes
     if (idx >= nplane * sp.nz) return;
-    const int jx = (int)(idx % Mx), jy = (int)((idx / Mx) % My), jz = sp.z0 + (int)(idx / nplane);
+    const unsigned row = idx / (unsigned)Mx;
+    const int jx = (int)(idx - row * Mx), jy = (int)(row % (unsigned)My), jz = sp.z0 + (int)(row / (unsigned)My);
     int tix[3], lix[3], tiy[3], liy[3], tiz[3], liz[3];
     const int nx = axis_sources<P>(jx, Mx, tix, lix), ny = axis_sources<P>(jy, My, tiy, liy), nz = axis_sources<P>(jz, sp.M[2], tiz, liz);
     double sum = 0.0;
