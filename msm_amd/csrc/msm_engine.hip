@@ -84,8 +84,8 @@ struct msm_amd_handle {
                               // level-0 convolution runs), and cross-stream waits stalled with 4 processes sharing one GPU
     hipEvent_t ev_fork = nullptr, ev_pairs = nullptr, ev_join = nullptr;
     int opt_overlap = 0; // measured: +5 % evaluations/s, but the pair kernel's workgroups starve the large convolution blocks
-    int opt_transfer_fused = 3;              // restriction: 3 tiled through LDS in one launch (default), 0 separable passes; 1, 2 (thread per node,
-                                             // also for the prolongation): slower at every size measured
+    int opt_transfer_fused = 4;              // 4: restriction and prolongation tiled through LDS, one launch per level (default); 3: restriction
+                                             // only; 0: separable passes; 1, 2: thread per node, slower at every size measured
     long opt_transfer_fused_max = 1L << 30;
 };
 
@@ -594,7 +594,7 @@ static bool transfer_fused(const msm_amd_handle *h, int l) {
 static void restrict_level(msm_amd_handle *h, int l, const double *fine, double *coarse) {
     const int p = h->hp.d.p;
     int m0[3] = {h->hp.Ml[l][0], h->hp.Ml[l][1], h->hp.Ml[l][2]};
-    if (h->opt_transfer_fused == 3) { launch_restrict_tiled(h->stream, fine, coarse, m0, p, h->hp.J); return; }
+    if (h->opt_transfer_fused >= 3) { launch_restrict_tiled(h->stream, fine, coarse, m0, p, h->hp.J); return; }
     if (transfer_fused(h, l)) { launch_restrict3(h->stream, fine, coarse, m0, p, h->hp.J); return; }
     launch_restrict_axis(h->stream, fine, h->tmpA, m0, 0, p, h->hp.J);
     int m1[3] = {m0[0] / 2, m0[1], m0[2]};
@@ -604,6 +604,11 @@ static void restrict_level(msm_amd_handle *h, int l, const double *fine, double 
 }
 static void prolong_level_add(msm_amd_handle *h, int l, const double *coarse, double *fine) {
     const int p = h->hp.d.p;
+    if (h->opt_transfer_fused == 4) {
+        int m0[3] = {h->hp.Ml[l][0], h->hp.Ml[l][1], h->hp.Ml[l][2]};
+        launch_prolong_tiled_add(h->stream, coarse, fine, m0, p, h->hp.J);
+        return;
+    }
     if (transfer_fused(h, l)) {
         int m0[3] = {h->hp.Ml[l][0], h->hp.Ml[l][1], h->hp.Ml[l][2]};
         launch_prolong3_add(h->stream, coarse, fine, m0, p, h->hp.J);

@@ -989,16 +989,17 @@ void launch_prolong3_add(hipStream_t st, const double *coarse, double *fine, con
 // from LDS to LDS and the third to global memory.  The passes recompute a halo, which is cheap next to two
 // launches, and every value is formed by the same operations in the same order as in the separate passes.
 // (The same construction for the prolongation was measured slower than its three separate passes.)
-#define TR_T 8  // coarse nodes per tile edge
+#define TR_T 4         // coarse nodes per tile edge: small tiles, so that even a 24^3 grid gives every CU work
+#define TR_THREADS 128
 template <int H>
-__global__ __launch_bounds__(256) void k_restrict_tiled(const double *__restrict__ fine, double *__restrict__ coarse, Transfer3 t) {
+__global__ __launch_bounds__(TR_THREADS) void k_restrict_tiled(const double *__restrict__ fine, double *__restrict__ coarse, Transfer3 t) {
     constexpr int NF = 2 * TR_T - 1 + 2 * H; // fine nodes per axis under a tile of coarse nodes
     __shared__ double t1[NF][NF][TR_T];      // [z fine][y fine][x coarse]
     __shared__ double t2[NF][TR_T][TR_T];    // [z fine][y coarse][x coarse]
     const int ntx = (t.Mc[0] + TR_T - 1) / TR_T, nty = (t.Mc[1] + TR_T - 1) / TR_T;
     const int X0 = (blockIdx.x % ntx) * TR_T, Y0 = ((blockIdx.x / ntx) % nty) * TR_T, Z0 = (blockIdx.x / (ntx * nty)) * TR_T;
     // x: t1[zi][yi][xc] = sum_j J|j| fine[2 (X0 + xc) + j, 2 Y0 - H + yi, 2 Z0 - H + zi]
-    for (int o = threadIdx.x; o < NF * NF * TR_T; o += 256) {
+    for (int o = threadIdx.x; o < NF * NF * TR_T; o += TR_THREADS) {
         const int xc = o % TR_T, yi = (o / TR_T) % NF, zi = o / (TR_T * NF);
         const double *row = fine + ((size_t)modp(2 * Z0 - H + zi, t.Mf[2]) * t.Mf[1] + modp(2 * Y0 - H + yi, t.Mf[1])) * t.Mf[0];
         const int m = X0 + xc;
@@ -1009,7 +1010,7 @@ __global__ __launch_bounds__(256) void k_restrict_tiled(const double *__restrict
     }
     __syncthreads();
     // y: t2[zi][yc][xc] = sum_j J|j| t1[zi][2 yc + j + H][xc]
-    for (int o = threadIdx.x; o < NF * TR_T * TR_T; o += 256) {
+    for (int o = threadIdx.x; o < NF * TR_T * TR_T; o += TR_THREADS) {
         const int xc = o % TR_T, yc = (o / TR_T) % TR_T, zi = o / (TR_T * TR_T);
         double s = 0.0;
 #pragma unroll
@@ -1018,7 +1019,7 @@ __global__ __launch_bounds__(256) void k_restrict_tiled(const double *__restrict
     }
     __syncthreads();
     // z: coarse[X0 + xc, Y0 + yc, Z0 + zc] = sum_j J|j| t2[2 zc + j + H][yc][xc]
-    for (int o = threadIdx.x; o < TR_T * TR_T * TR_T; o += 256) {
+    for (int o = threadIdx.x; o < TR_T * TR_T * TR_T; o += TR_THREADS) {
         const int xc = o % TR_T, yc = (o / TR_T) % TR_T, zc = o / (TR_T * TR_T);
         if (X0 + xc >= t.Mc[0] || Y0 + yc >= t.Mc[1] || Z0 + zc >= t.Mc[2]) continue;
         double s = 0.0;
@@ -1028,11 +1029,74 @@ __global__ __launch_bounds__(256) void k_restrict_tiled(const double *__restrict
     }
 }
 
+// The prolongation the same way: z, then y, then x (the order of the separate passes), along an axis
+// out[n] = sum_{|j| <= H, n - j even} J|j| in[(n - j) / 2].  Small tiles (8^3 fine nodes): with large ones a grid
+// has fewer tiles than the chip has CUs and the three dependent passes of a workgroup are not hidden by anything.
+#define PR_T 8 // fine nodes per tile edge
+template <int H>
+__global__ __launch_bounds__(128) void k_prolong_tiled(const double *__restrict__ coarse, double *__restrict__ fine, Transfer3 t) {
+    constexpr int TF = PR_T, NC = PR_T / 2 + 4; // coarse nodes per axis that reach a tile: X0/2 - 2 .. X0/2 + TF/2 + 1 (H <= 3)
+    constexpr int NP = NC + 1;
+    __shared__ double t1[TF][NC][NP]; // [z fine][y coarse][x coarse]
+    __shared__ double t2[TF][TF][NP]; // [z fine][y fine][x coarse]
+    const int ntx = (t.Mf[0] + TF - 1) / TF, nty = (t.Mf[1] + TF - 1) / TF;
+    const int X0 = (blockIdx.x % ntx) * TF, Y0 = ((blockIdx.x / ntx) % nty) * TF, Z0 = (blockIdx.x / (ntx * nty)) * TF;
+    const int cx0 = X0 / 2 - 2, cy0 = Y0 / 2 - 2;
+    const size_t plane = (size_t)t.Mc[0] * t.Mc[1];
+    for (int o = threadIdx.x; o < TF * NC * NC; o += 128) {
+        const int xi = o % NC, yi = (o / NC) % NC, zf = o / (NC * NC);
+        const double *col = coarse + (size_t)modp(cy0 + yi, t.Mc[1]) * t.Mc[0] + modp(cx0 + xi, t.Mc[0]);
+        const int n = Z0 + zf;
+        double s = 0.0;
+#pragma unroll
+        for (int j = -H; j <= H; j++) {
+            const int u = n - j;
+            if (u & 1) continue;
+            s = fma(t.J[j < 0 ? -j : j], col[(size_t)modp(u / 2, t.Mc[2]) * plane], s);
+        }
+        t1[zf][yi][xi] = s;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < TF * TF * NC; o += 128) {
+        const int xi = o % NC, yf = (o / NC) % TF, zf = o / (NC * TF);
+        const int n = Y0 + yf;
+        double s = 0.0;
+#pragma unroll
+        for (int j = -H; j <= H; j++) {
+            const int u = n - j;
+            if (u & 1) continue;
+            s = fma(t.J[j < 0 ? -j : j], t1[zf][u / 2 - cy0][xi], s);
+        }
+        t2[zf][yf][xi] = s;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < TF * TF * TF; o += 128) {
+        const int xf = o % TF, yf = (o / TF) % TF, zf = o / (TF * TF);
+        if (X0 + xf >= t.Mf[0] || Y0 + yf >= t.Mf[1] || Z0 + zf >= t.Mf[2]) continue;
+        const int n = X0 + xf;
+        double s = 0.0;
+#pragma unroll
+        for (int j = -H; j <= H; j++) {
+            const int u = n - j;
+            if (u & 1) continue;
+            s = fma(t.J[j < 0 ? -j : j], t2[zf][yf][u / 2 - cx0], s);
+        }
+        const size_t idx = ((size_t)(Z0 + zf) * t.Mf[1] + (Y0 + yf)) * t.Mf[0] + (X0 + xf);
+        fine[idx] = fine[idx] + s;
+    }
+}
+void launch_prolong_tiled_add(hipStream_t st, const double *coarse, double *fine, const int Mf[3], int p, const double J[4]) {
+    const Transfer3 t = make_transfer(Mf, p, J);
+    const int nb = ((t.Mf[0] + PR_T - 1) / PR_T) * ((t.Mf[1] + PR_T - 1) / PR_T) * ((t.Mf[2] + PR_T - 1) / PR_T);
+    if (p == 4) hipLaunchKernelGGL((k_prolong_tiled<2>), dim3(nb), dim3(128), 0, st, coarse, fine, t);
+    else hipLaunchKernelGGL((k_prolong_tiled<3>), dim3(nb), dim3(128), 0, st, coarse, fine, t);
+}
+
 void launch_restrict_tiled(hipStream_t st, const double *fine, double *coarse, const int Mf[3], int p, const double J[4]) {
     const Transfer3 t = make_transfer(Mf, p, J);
     const int nb = ((t.Mc[0] + TR_T - 1) / TR_T) * ((t.Mc[1] + TR_T - 1) / TR_T) * ((t.Mc[2] + TR_T - 1) / TR_T);
-    if (p == 4) hipLaunchKernelGGL((k_restrict_tiled<2>), dim3(nb), dim3(256), 0, st, fine, coarse, t);
-    else hipLaunchKernelGGL((k_restrict_tiled<3>), dim3(nb), dim3(256), 0, st, fine, coarse, t);
+    if (p == 4) hipLaunchKernelGGL((k_restrict_tiled<2>), dim3(nb), dim3(TR_THREADS), 0, st, fine, coarse, t);
+    else hipLaunchKernelGGL((k_restrict_tiled<3>), dim3(nb), dim3(TR_THREADS), 0, st, fine, coarse, t);
 }
 // ---------------------------------------------------------------------------
 // grid convolution

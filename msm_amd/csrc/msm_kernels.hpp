@@ -158,6 +158,7 @@ struct ConvBatch {
 };
 // the three axis passes of a restriction in one launch, tile by tile through LDS (same bits as the separate passes)
 void launch_restrict_tiled(hipStream_t st, const double *fine, double *coarse, const int Mf[3], int p, const double J[4]);
+void launch_prolong_tiled_add(hipStream_t st, const double *coarse, double *fine, const int Mf[3], int p, const double J[4]);
 bool launch_conv_multi(hipStream_t st, ConvBatch &B);
 // coarsest level + Fourier level, both full-period, as offset tables Ta (sum) and Tb (Fourier part): ea = Ta * q, eb = Tb * q
 void launch_conv_small_pair(hipStream_t st, const double *q, const double *Ta, const double *Tb, const int M[3], double *ea,

@@ -103,14 +103,14 @@ def test_stagewise_parity(msm, torch, N, A, p, mu, L):
         coarse = torch.zeros((d[2], d[1], d[0]), dtype=torch.float64, device=dev)
         co = sp.restrict(l, grids_q[l])
         got = []
-        for fused in (0, 1, 3):    # three separable passes / one thread per node / tiles through LDS: the same bits
+        for fused in (0, 1, 4):    # three separable passes / one thread per node / tiles through LDS: the same bits
             eng.set_option("transfer_fused", fused)
             coarse.zero_()
             eng.op_restrict(l, fine, coarse)
             got.append(coarse.cpu().numpy().copy())
             assert grid_err(got[-1], co) < TOL
         assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
-        eng.set_option("transfer_fused", 3)
+        eng.set_option("transfer_fused", 4)
         grids_q.append(co)
     for l in range(L):
         qg = torch.as_tensor(grids_q[l], device=dev)
@@ -134,14 +134,14 @@ def test_stagewise_parity(msm, torch, N, A, p, mu, L):
         c = rng.standard_normal((d1[2], d1[1], d1[0]))
         f = rng.standard_normal((d0[2], d0[1], d0[0]))
         got = []
-        for fused in (0, 1, 3):
+        for fused in (0, 1, 4):
             eng.set_option("transfer_fused", fused)
             fd = torch.as_tensor(f, device=dev)
             eng.op_prolong_add(0, torch.as_tensor(c, device=dev), fd)
             got.append(fd.cpu().numpy().copy())
             assert grid_err(got[-1], sp.prolong_add(0, c, f)) < TOL
         assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
-        eng.set_option("transfer_fused", 3)
+        eng.set_option("transfer_fused", 4)
 
     # whole grid stage, interpolation, energies
     eng.stage_grid()
