@@ -51,8 +51,8 @@ def make_system(N, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--particles", type=int, default=1000000)
     ap.add_argument("--order", type=int, default=6, choices=(4, 6))
     ap.add_argument("--levels", type=int, default=0, help="grid levels (0: the reference's formula, capped)")

@@ -77,6 +77,7 @@ struct msm_amd_handle {
     bool anterp_tiled = false;
     int opt_anterp_tiled = 1;
     // second stream: the grid pipeline runs beside the list build and the pair kernel
+    double *energies_alias = nullptr; // device-visible host slot the energies of the evaluation in flight go to
     hipStream_t stream_b = nullptr;
     hipStream_t stream_g = nullptr; // coarse-level branch of the grid stage
     hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr;
@@ -794,7 +795,7 @@ static int queue_energies(msm_amd_handle *h, bool raw = false) {
     in.gamma0_over_a = h->hp.gamma0 / d.a;
     in.literal = h->hp.literal ? 1 : 0;
     if (raw) launch_raw_sums(h->stream, in, h->d_energies);
-    else launch_finalize_energies(h->stream, in, h->d_energies);
+    else launch_finalize_energies(h->stream, in, h->d_energies, h->energies_alias);
     HIPCHK(hipGetLastError());
     return MSM_AMD_OK;
 }
@@ -932,9 +933,22 @@ extern "C" int msm_amd_eval(msm_amd_handle *h, const double *d_r, const double *
 
 extern "C" int msm_amd_eval_enqueue(msm_amd_handle *h, const double *d_r, const double *d_q, double *d_acc,
                                     double *host_energies) {
+    if (!h) return MSM_AMD_EINVAL;
+    // pinned (device-visible) host memory: the last kernel of the evaluation writes the energies there itself;
+    // anything else gets a copy command behind the evaluation
+    double *alias = nullptr;
+    if (host_energies) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, host_energies) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer)
+            alias = (double *)at.devicePointer;
+        else
+            (void)hipGetLastError();
+    }
+    h->energies_alias = alias;
     int rc = msm_amd_eval(h, d_r, d_q, d_acc, nullptr);
+    h->energies_alias = nullptr;
     if (rc) return rc;
-    if (host_energies)
+    if (host_energies && !alias)
         HIPCHK(hipMemcpyAsync(host_energies, h->d_energies, MSM_AMD_U_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     return MSM_AMD_OK;
 }

@@ -1627,7 +1627,7 @@ void launch_energy_partials(hipStream_t st, const EnergyPartialsArgs &a, int npa
 }
 
 // (A)..(F) and the total (msmPeriodic.c:1305-1359; msmSimple.c:1968-1969)
-__global__ __launch_bounds__(256) void k_finalize_energies(EnergyInputs in, double *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_finalize_energies(EnergyInputs in, double *__restrict__ out, double *__restrict__ out2) {
     __shared__ double red[256];
     const double ua = sum_array(in.pair_parts, in.n_pair, red);
     const double qe = sum_array(in.grid_parts, in.n_grid, red);
@@ -1651,6 +1651,8 @@ __global__ __launch_bounds__(256) void k_finalize_energies(EnergyInputs in, doub
         out[MSM_AMD_U_LONG_SELF] = -0.5 * qs2 * in.gamma0_over_a;
         out[MSM_AMD_U_TOTAL] = (ulf + ulr + out[MSM_AMD_U_LONG_SELF]) +
                                (ua + out[MSM_AMD_U_SHORT_SELF] + out[MSM_AMD_U_SHORT_CSR]);
+        if (out2) // a second copy, e.g. straight into device-visible host memory (saves a copy command)
+            for (int k = 0; k < MSM_AMD_U_COUNT; k++) out2[k] = out[k];
     }
 }
 __global__ __launch_bounds__(256) void k_raw_sums(EnergyInputs in, double *__restrict__ out) {
@@ -1665,8 +1667,8 @@ __global__ __launch_bounds__(256) void k_raw_sums(EnergyInputs in, double *__res
 void launch_raw_sums(hipStream_t st, const EnergyInputs &in, double *out5) {
     hipLaunchKernelGGL(k_raw_sums, dim3(1), dim3(256), 0, st, in, out5);
 }
-void launch_finalize_energies(hipStream_t st, const EnergyInputs &in, double *out7) {
-    hipLaunchKernelGGL(k_finalize_energies, dim3(1), dim3(256), 0, st, in, out7);
+void launch_finalize_energies(hipStream_t st, const EnergyInputs &in, double *out7, double *out7_second) {
+    hipLaunchKernelGGL(k_finalize_energies, dim3(1), dim3(256), 0, st, in, out7, out7_second);
 }
 
 } // namespace msm

@@ -199,7 +199,7 @@ struct EnergyPartialsArgs {
     const double *p_in; int p_n; double *p_parts;
 };
 void launch_energy_partials(hipStream_t st, const EnergyPartialsArgs &a, int nparts);
-void launch_finalize_energies(hipStream_t st, const EnergyInputs &in, double *out7);
+void launch_finalize_energies(hipStream_t st, const EnergyInputs &in, double *out7, double *out7_second = nullptr);
 // raw sums for a slab rank: out5 = [pair sum, q0.e0 over owned planes, qL.efour, sum q, sum q^2]
 void launch_raw_sums(hipStream_t st, const EnergyInputs &in, double *out5);
 
