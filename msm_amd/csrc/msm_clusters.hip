@@ -174,8 +174,9 @@ struct ColCursor {
     int sxy;      // (px+1) + 3 (py+1): periods the column was wrapped by
     float ilx, ihx, ily, ihy; // the i box along x and y, shifted back by the column's image shift
     int zf0, zf1; // extended fine-bin range to visit
-    int k;        // current z period (-1, 0, 1); -2 before the first segment
-    int cur, end; // clusters [cur, end] of the current segment
+    int k;        // z period (-1, 0, 1) of the current candidate
+    // all three z periods at once (cl_ranges): first cluster and number of clusters of each, none = 0
+    int b0, b1, b2, n0, n1, n2;
 };
 
 __device__ __forceinline__ bool cl_column(const ClusterGeom &g, double a2, const IBox &ib, int exi, int eyi, ColCursor &c) {
@@ -197,28 +198,33 @@ __device__ __forceinline__ bool cl_column(const ClusterGeom &g, double a2, const
     c.ily = __double2float_rd(ib.loy) - sy; c.ihy = __double2float_ru(ib.hiy) - sy;
     c.zf0 = (int)floor((ib.loz - az) * g.inv_dzf - eps);
     c.zf1 = (int)floor((ib.hiz + az) * g.inv_dzf + eps);
-    c.k = -2;
-    c.cur = 1;
-    c.end = 0;
+    c.k = 0;
     return true;
 }
 
-__device__ __forceinline__ bool cl_next_segment(const ClusterGeom &g, const int *__restrict__ start,
-                                                const int *__restrict__ clstart, ColCursor &c) {
-    while (c.k < 1) {
-        c.k = c.k < -1 ? -1 : c.k + 1;
-        const int off = c.k * g.nzf;
+// The cluster ranges of the three z periods of a column, computed once: the walk over a column then needs no
+// control flow of its own (candidate t of the lane is found from the three lengths by two comparisons).
+__device__ __forceinline__ void cl_ranges(const ClusterGeom &g, const int *__restrict__ start, const int *__restrict__ clstart,
+                                          ColCursor &c) {
+    const int base = c.col * g.nzf;
+    const int colp0 = start[base], c0 = clstart[c.col];
+    int bb[3], nn[3];
+#pragma unroll
+    for (int k = -1; k <= 1; k++) {
+        const int off = k * g.nzf;
         const int lo = max(c.zf0, off) - off, hi = min(c.zf1, off + g.nzf - 1) - off;
-        if (lo > hi) continue;
-        const int base = c.col * g.nzf;
-        const int colp0 = start[base], p0 = start[base + lo], p1 = start[base + hi + 1];
-        if (p1 <= p0) continue;
-        const int c0 = clstart[c.col];
-        c.cur = c0 + (p0 - colp0) / CL_G;
-        c.end = c0 + (p1 - 1 - colp0) / CL_G;
-        return true;
+        bb[k + 1] = 0;
+        nn[k + 1] = 0;
+        if (lo <= hi) {
+            const int p0 = start[base + lo], p1 = start[base + hi + 1];
+            if (p1 > p0) {
+                bb[k + 1] = c0 + (p0 - colp0) / CL_G;
+                nn[k + 1] = (p1 - 1 - colp0) / CL_G - (p0 - colp0) / CL_G + 1;
+            }
+        }
     }
-    return false;
+    c.b0 = bb[0]; c.b1 = bb[1]; c.b2 = bb[2];
+    c.n0 = nn[0]; c.n1 = nn[1]; c.n2 = nn[2];
 }
 
 // Calls emit(keep, jcl, code) with all 64 lanes converged; each lane brings its own candidate.
@@ -233,15 +239,21 @@ __device__ __forceinline__ void cl_enumerate(const ClusterGeom &g, const Cluster
     for (int by = ey0; by <= ey1; by += 8)
     for (int bx = ex0; bx <= ex1; bx += 8) {
         ColCursor c;
-        bool live = false;
         const int exi = bx + (lane & 7), eyi = by + (lane >> 3);
-        if (exi <= ex1 && eyi <= ey1 && cl_column(g, a2, ib, exi, eyi, c)) live = cl_next_segment(g, b.start, b.clstart, c);
-        while (__ballot(live)) {
+        int total = 0;
+        if (exi <= ex1 && eyi <= ey1 && cl_column(g, a2, ib, exi, eyi, c)) {
+            cl_ranges(g, b.start, b.clstart, c);
+            total = c.n0 + c.n1 + c.n2;
+        }
+        for (int t = 0; __ballot(t < total); t++) {
+            const bool live = t < total;
             int jcl = 0, code = CL_NOSHIFT;
             bool keep = false;
             if (live) {
-                jcl = c.cur;
-                code = c.sxy + 9 * (c.k + 1);
+                const int seg = (t >= c.n0) + (t >= c.n0 + c.n1);
+                jcl = seg == 0 ? c.b0 + t : (seg == 1 ? c.b1 + (t - c.n0) : c.b2 + (t - c.n0 - c.n1));
+                c.k = seg - 1;
+                code = c.sxy + 9 * seg;
                 // single-precision boxes against the single-precision i box shifted back by the image shift;
                 // the widened cutoff keeps the test conservative
                 const float4 jl = b.fbox[2 * (size_t)jcl], jh = b.fbox[2 * (size_t)jcl + 1];
@@ -252,7 +264,6 @@ __device__ __forceinline__ void cl_enumerate(const ClusterGeom &g, const Cluster
                 keep = gx * gx + gy * gy + gz * gz < g.a2_wide;
             }
             emit(keep, jcl, code);
-            if (live && ++c.cur > c.end) live = cl_next_segment(g, b.start, b.clstart, c);
         }
     }
 }
