@@ -1469,7 +1469,7 @@ bool launch_conv_multi(hipStream_t st, ConvBatch &B) {
     case 9: return conv_multi_launch<9, 8, 16, 8, 16, 9>(st, B);
     case 11: return conv_multi_launch<11, 8, 16, 8, 16, 11>(st, B);
     case 13: return conv_multi_launch<13, 8, 16, 8, 16, 13>(st, B);
-    case 15: return conv_multi_launch<15, 8, 16, 8, 16, 15>(st, B);
+    case 15: return conv_multi_launch<15, 8, 16, 8, 16, 3>(st, B); // 30 x 10 x 30: two workgroups per CU (2 % faster than the whole halo at once)
     case 17: return conv_multi_launch<17, 8, 16, 8, 16, 11>(st, B); // 32 x 18 x 32 doubles
     case 19: return conv_multi_launch<19, 8, 16, 8, 16, 7>(st, B);  // 34 x 14 x 34
     case 21: return conv_multi_launch<21, 8, 16, 8, 16, 7>(st, B);  // 36 x 14 x 36
