@@ -143,8 +143,253 @@ __global__ void k_cl_bbox(ClusterGeom g, ClusterBuffers b) {
     b.fbox[2 * (size_t)k + 1] = make_float4(__double2float_ru(h[0]), __double2float_ru(h[1]), __double2float_ru(h[2]), 0.f);
 }
 
+// ---------------------------------------------------------------------------
+// The same sort in two levels, without one global counter per fine bin.  (Device-wide atomics are resolved beyond the
+// per-XCD L2 and a million of them take 40 us; the finishing pass of that sort gathers every particle again.)
+//   1. every workgroup counts the particles of its share per column in LDS;
+//   2. per column, the counts are scanned over the workgroups; columns are scanned over the grid;
+//   3. every workgroup drops its particles into the buckets of their columns (position inside a bucket: an LDS
+//      counter, i.e. arbitrary);
+//   4. one workgroup per column ranks the bucket by (fine z bin, original index) - the order the other sort
+//      produces, so everything downstream sees the same bits - writes the slots, the padding, the prefix sums
+//      over the fine bins and the bounding boxes of the column's clusters.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int cl_bin_of(const double *__restrict__ r, int i, const ClusterGeom &g) {
+    double s[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        double t = r[3 * (size_t)i + d] * g.invA[d];
+        s[d] = t - floor(t);
+    }
+    const int cx = g.kx ? min((int)(s[0] * (g.ncx * g.kx)), g.ncx * g.kx - 1) / g.kx : min((int)(s[0] * g.ncx), g.ncx - 1);
+    const int cy = g.ky ? min((int)(s[1] * (g.ncy * g.ky)), g.ncy * g.ky - 1) / g.ky : min((int)(s[1] * g.ncy), g.ncy - 1);
+    const int zf = min((int)(s[2] * g.nzf), g.nzf - 1);
+    return cl_col(g, cx, cy) * g.nzf + zf;
+}
+
+__global__ __launch_bounds__(256) void k_cs_hist(const double *__restrict__ r, int N, ClusterGeom g, int per_block,
+                                                 int *__restrict__ bin_of, int *__restrict__ hist) {
+    extern __shared__ int lh[];
+    for (int c = threadIdx.x; c < g.ncols; c += 256) lh[c] = 0;
+    __syncthreads();
+    const int i0 = blockIdx.x * per_block, i1 = min(N, i0 + per_block);
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int b = cl_bin_of(r, i, g);
+        bin_of[i] = b;
+        atomicAdd(&lh[b / g.nzf], 1);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < g.ncols; c += 256) hist[(size_t)blockIdx.x * g.ncols + c] = lh[c];
+}
+
+// hist[blk][col] -> particles of the column in earlier workgroups; coltotal[col].  64 columns per workgroup (coalesced
+// rows of hist), the workgroups of the histogram cut into 16 segments that are summed side by side.
+__global__ __launch_bounds__(1024) void k_cs_blockscan(int *__restrict__ hist, int nblk, int ncols, int *__restrict__ coltotal) {
+    __shared__ int seg[16][64];
+    const int cx = threadIdx.x & 63, s = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int per = (nblk + 15) / 16, k0 = min(nblk, s * per), k1 = min(nblk, k0 + per);
+    int sum = 0;
+    if (c < ncols)
+        for (int k = k0; k < k1; k++) sum += hist[(size_t)k * ncols + c];
+    seg[s][cx] = sum;
+    __syncthreads();
+    if (c >= ncols) return;
+    int run = 0;
+    for (int t = 0; t < s; t++) run += seg[t][cx];
+    for (int k = k0; k < k1; k++) {
+        const int v = hist[(size_t)k * ncols + c];
+        hist[(size_t)k * ncols + c] = run;
+        run += v;
+    }
+    if (s == 15) coltotal[c] = run;
+}
+
+// exclusive scans over the columns of the particle counts (cpstart) and of the cluster counts (clstart), one workgroup
+__global__ __launch_bounds__(1024) void k_cs_colscan(const int *__restrict__ coltotal, ClusterGeom g, int *__restrict__ colncl,
+                                                     int *__restrict__ clstart, int *__restrict__ cpstart) {
+    __shared__ int wsum[2][16];
+    __shared__ int carry[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 2) carry[threadIdx.x] = 0;
+    __syncthreads();
+    for (int base = 0; base < g.ncols; base += 1024) {
+        const int col = base + threadIdx.x;
+        int vp = 0, vc = 0;
+        if (col < g.ncols) {
+            vp = coltotal[col];
+            vc = (vp + CL_G - 1) / CL_G;
+            colncl[col] = vc;
+        }
+        int ip = vp, ic = vc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int tp = __shfl_up(ip, off), tc = __shfl_up(ic, off);
+            if (lane >= off) { ip += tp; ic += tc; }
+        }
+        if (lane == 63) { wsum[0][wave] = ip; wsum[1][wave] = ic; }
+        __syncthreads();
+        int bp = carry[0], bc = carry[1];
+        for (int w = 0; w < wave; w++) { bp += wsum[0][w]; bc += wsum[1][w]; }
+        if (col < g.ncols) { cpstart[col] = bp + ip - vp; clstart[col] = bc + ic - vc; }
+        __syncthreads();
+        if (threadIdx.x == 1023) { carry[0] = bp + ip; carry[1] = bc + ic; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { cpstart[g.ncols] = carry[0]; clstart[g.ncols] = carry[1]; }
+}
+
+__global__ __launch_bounds__(256) void k_cs_scatter(const double *__restrict__ r, const double *__restrict__ q, int N, ClusterGeom g,
+                                                    int per_block, const int *__restrict__ bin_of, const int *__restrict__ hist,
+                                                    const int *__restrict__ cpstart, double4 *__restrict__ bps,
+                                                    int *__restrict__ bidx, int *__restrict__ bzf) {
+    extern __shared__ int cursor[];
+    for (int c = threadIdx.x; c < g.ncols; c += 256) cursor[c] = cpstart[c] + hist[(size_t)blockIdx.x * g.ncols + c];
+    __syncthreads();
+    const int i0 = blockIdx.x * per_block, i1 = min(N, i0 + per_block);
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int b = bin_of[i], col = b / g.nzf;
+        const int pos = atomicAdd(&cursor[col], 1);
+        double f[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            double t = r[3 * (size_t)i + d] * g.invA[d];
+            f[d] = (t - floor(t)) * g.A[d];
+        }
+        bps[pos] = make_double4(f[0], f[1], f[2], q[i]);
+        bidx[pos] = i;
+        bzf[pos] = b - col * g.nzf;
+    }
+}
+
+#define CS_CHUNK 1024
+#define CS_CAP 3072
+__global__ __launch_bounds__(256) void k_cs_colsort(ClusterGeom g, ClusterBuffers b) {
+    extern __shared__ int zh[];                       // particles per fine bin of the column; zs = zh + nzf: their exclusive scan
+    __shared__ union {
+        unsigned long long keys[CS_CHUNK];            // (fine bin, original index) of a chunk of a long bucket
+        int member[CS_CAP];                           // original indices, grouped by fine bin (any order inside a bin)
+    } u;
+    __shared__ int wtot[4];
+    __shared__ int carry;
+    int *zs = zh + g.nzf;
+    const int col = blockIdx.x;
+    const int p0 = b.cpstart[col], n = b.cpstart[col + 1] - p0, c0 = b.clstart[col], ncl = b.colncl[col];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int z = threadIdx.x; z < g.nzf; z += 256) zh[z] = 0;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < n; e += 256) atomicAdd(&zh[b.bzf[p0 + e]], 1);
+    __syncthreads();
+    // zs[z] = particles of the column in fine bins below z; start[col * nzf + z] = p0 + zs[z]
+    for (int base = 0; base < g.nzf; base += 256) {
+        const int z = base + threadIdx.x;
+        const int v = z < g.nzf ? zh[z] : 0;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wave; w++) before += wtot[w];
+        if (z < g.nzf) {
+            zs[z] = before + incl - v;
+            b.start[(size_t)col * g.nzf + z] = p0 + before + incl - v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) carry = before + incl;
+        __syncthreads();
+    }
+    if (col == g.ncols - 1 && threadIdx.x == 0) b.start[(size_t)g.ncols * g.nzf] = p0 + n;
+    // rank of a particle inside the column: particles in lower fine bins + particles of its bin with a lower original index
+    if (n <= CS_CAP) {
+        for (int z = threadIdx.x; z < g.nzf; z += 256) zh[z] = 0;
+        __syncthreads();
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int z = b.bzf[p0 + e];
+            u.member[zs[z] + atomicAdd(&zh[z], 1)] = b.bidx[p0 + e];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int z = b.bzf[p0 + e], idx = b.bidx[p0 + e];
+            const int m0 = zs[z], m1 = m0 + zh[z];
+            int rank = m0;
+            for (int m = m0; m < m1; m++) rank += u.member[m] < idx;
+            const size_t dst = (size_t)CL_G * c0 + rank;
+            b.ps[dst] = b.bps[p0 + e];
+            b.order[dst] = idx;
+        }
+    } else {
+        // a bucket too long for the LDS copy: rank among the keys of the whole bucket, a chunk at a time
+        for (int e0 = 0; e0 < n; e0 += 256) {
+            const int e = e0 + threadIdx.x;
+            unsigned long long key = 0;
+            if (e < n) key = ((unsigned long long)(unsigned)b.bzf[p0 + e] << 32) | (unsigned)b.bidx[p0 + e];
+            int rank = 0;
+            for (int j0 = 0; j0 < n; j0 += CS_CHUNK) {
+                const int m = min(CS_CHUNK, n - j0);
+                __syncthreads();
+                for (int j = threadIdx.x; j < m; j += 256)
+                    u.keys[j] = ((unsigned long long)(unsigned)b.bzf[p0 + j0 + j] << 32) | (unsigned)b.bidx[p0 + j0 + j];
+                __syncthreads();
+                if (e < n)
+                    for (int j = 0; j < m; j++) rank += u.keys[j] < key;
+            }
+            if (e < n) {
+                const size_t dst = (size_t)CL_G * c0 + rank;
+                b.ps[dst] = b.bps[p0 + e];
+                b.order[dst] = (int)(unsigned)key;
+            }
+        }
+    }
+    // padding of the column's last cluster
+    for (int m = n + threadIdx.x; m < CL_G * ncl; m += 256) {
+        b.ps[(size_t)CL_G * c0 + m] = make_double4(g.far, g.far, g.far, 0.0);
+        b.order[(size_t)CL_G * c0 + m] = CL_DUMMY;
+    }
+    if (col == 0 && threadIdx.x < CL_G) // one cluster of inert slots behind the last possible cluster (see k_cl_bbox)
+        b.ps[(size_t)CL_G * g.max_clusters + threadIdx.x] = make_double4(g.far, g.far, g.far, 0.0);
+    __syncthreads();
+    // bounding boxes of the column's clusters (the slots were written by this workgroup: visible after the barriers)
+    for (int k = threadIdx.x; k < ncl; k += 256) {
+        const int nin = min(CL_G, n - CL_G * k);
+        const double4 *p = b.ps + (size_t)CL_G * (c0 + k);
+        double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+        for (int m = 0; m < nin; m++) {
+            const double4 v = p[m];
+            l[0] = fmin(l[0], v.x); h[0] = fmax(h[0], v.x);
+            l[1] = fmin(l[1], v.y); h[1] = fmax(h[1], v.y);
+            l[2] = fmin(l[2], v.z); h[2] = fmax(h[2], v.z);
+        }
+        const int kk = c0 + k;
+        b.blo[kk] = make_double4(l[0], l[1], l[2], 0.0);
+        b.bhi[kk] = make_double4(h[0], h[1], h[2], 0.0);
+        b.fbox[2 * (size_t)kk] = make_float4(__double2float_rd(l[0]), __double2float_rd(l[1]), __double2float_rd(l[2]), 0.f);
+        b.fbox[2 * (size_t)kk + 1] = make_float4(__double2float_ru(h[0]), __double2float_ru(h[1]), __double2float_ru(h[2]), 0.f);
+    }
+}
+
+static void launch_cluster_sort2(hipStream_t st, const double *d_r, const double *d_q, int N, const ClusterGeom &g,
+                                 const ClusterBuffers &b, int *bin_of) {
+    const int nblk = g.sort_blocks, per_block = (N + nblk - 1) / nblk;
+    const size_t lds_cols = sizeof(int) * (size_t)g.ncols;
+    hipLaunchKernelGGL(k_cs_hist, dim3(nblk), dim3(256), lds_cols, st, d_r, N, g, per_block, bin_of, b.hist);
+    hipLaunchKernelGGL(k_cs_blockscan, dim3((g.ncols + 63) / 64), dim3(1024), 0, st, b.hist, nblk, g.ncols, b.coltotal);
+    hipLaunchKernelGGL(k_cs_colscan, dim3(1), dim3(1024), 0, st, b.coltotal, g, b.colncl, b.clstart, b.cpstart);
+    hipLaunchKernelGGL(k_cs_scatter, dim3(nblk), dim3(256), lds_cols, st, d_r, d_q, N, g, per_block, bin_of, b.hist, b.cpstart,
+                       b.bps, b.bidx, b.bzf);
+    hipLaunchKernelGGL(k_cs_colsort, dim3(g.ncols), dim3(256), 2 * sizeof(int) * (size_t)g.nzf, st, g, b);
+}
+
 void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, int N, const ClusterGeom &g,
                          const ClusterBuffers &b, int *bin_of, int *arrival, int *slot_idx, int *scan_tmp) {
+    if (g.sort_blocks > 0) {
+        launch_cluster_sort2(st, d_r, d_q, N, g, b, bin_of);
+        return;
+    }
     hipMemsetAsync(b.count, 0, sizeof(int) * (size_t)g.nbins, st);
     const int tb = 256, gb = (N + tb - 1) / tb;
     hipLaunchKernelGGL(k_cl_count, dim3(gb), dim3(tb), 0, st, d_r, N, g, bin_of, b.count, arrival);

@@ -49,6 +49,7 @@ struct msm_amd_handle {
     double *efour = nullptr, *dKL = nullptr, *tmpA = nullptr, *tmpB = nullptr;
     double *dTsum = nullptr, *dTfour = nullptr; // coarsest-level + Fourier stencils as offset tables (both span one period)
     int opt_top_fused = 1;
+    int opt_sort_two_level = 1; // creation-time choice (MSM_AMD_SORT=0 in the environment selects the sort with global counters)
     // reductions
     double *epart = nullptr;
     int nepart = 0;
@@ -296,6 +297,14 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
     if (!h->small_box) {
         ClusterBuffers &cb = h->clb;
         const size_t nslots = (size_t)cg.max_clusters * CL_G;
+        // two-level sort: needs the columns (and the fine bins of a column) to fit an LDS histogram
+        if (const char *e = getenv("MSM_AMD_SORT")) h->opt_sort_two_level = atoi(e) != 0; // A/B: 0 = one global counter per fine bin
+        cg.sort_blocks = (h->opt_sort_two_level && cg.ncols <= 12288 && cg.nzf <= 4096) ? std::max(1, std::min(512, (N + 2047) / 2048)) : 0;
+        h->clg.sort_blocks = cg.sort_blocks;
+        if (cg.sort_blocks) {
+            DA(cb.hist, (size_t)cg.sort_blocks * cg.ncols); DA(cb.coltotal, cg.ncols); DA(cb.cpstart, cg.ncols + 1);
+            DA(cb.bps, N); DA(cb.bidx, N); DA(cb.bzf, N);
+        }
         DA(cb.count, cg.nbins); DA(cb.start, cg.nbins + 1);
         DA(cb.colncl, cg.ncols + 1); DA(cb.clstart, cg.ncols + 1);
         DA(cb.order, nslots); DA(cb.ps, nslots + CL_G); // + one cluster of inert slots behind the last one
@@ -403,6 +412,7 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     hipFree(h->scan_tmp); hipFree(h->tile_scratch); hipFree(h->tile_used);
     {
         ClusterBuffers &cb = h->clb;
+        hipFree(cb.hist); hipFree(cb.coltotal); hipFree(cb.cpstart); hipFree(cb.bps); hipFree(cb.bidx); hipFree(cb.bzf);
         hipFree(cb.count); hipFree(cb.start); hipFree(cb.colncl); hipFree(cb.clstart); hipFree(cb.order);
         hipFree(cb.ps); hipFree(cb.blo); hipFree(cb.bhi); hipFree(cb.fbox); hipFree(cb.list); hipFree(cb.n0); hipFree(cb.n1); hipFree(cb.n2);
     }

@@ -83,6 +83,7 @@ struct ClusterGeom {
     double inv_dzf, dzf; // fine bins per unit length in z
     double far;          // coordinate given to padding slots
     float a2_wide;       // cutoff^2 widened to cover single-precision rounding in the box tests
+    int sort_blocks;     // workgroups of the two-level sort (0: the sort with one counter per fine bin is used)
 };
 struct ClusterBuffers {
     int *count, *start;         // per fine bin (start has nbins + 1 entries)
@@ -93,6 +94,11 @@ struct ClusterBuffers {
     float4 *fbox;               // the same rounded outwards to single precision: [2k] = low corner, [2k+1] = high corner
     int *list, *n0, *n1, *n2;   // neighbour-cluster lists: n0 entries (self + later clusters) from the front, n2 (earlier
                                 // clusters) from the middle, n1 (through a periodic image) from the back; n0 < 0: overflow
+    // two-level sort: per (workgroup, column) counts / offsets, particles per column and their exclusive scan, and the
+    // particles as they land in their column's bucket (any order inside a bucket)
+    int *hist, *coltotal, *cpstart;
+    double4 *bps;
+    int *bidx, *bzf;
 };
 void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, int N, const ClusterGeom &g,
                          const ClusterBuffers &b, int *bin_of, int *arrival, int *slot_idx, int *scan_tmp);
