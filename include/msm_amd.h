@@ -175,6 +175,14 @@ int msm_amd_get_mode(void);
 /* quiet != 0 suppresses the stencil / grid-charge dumps msmperiodic() prints in literal mode (msmPeriodic.c:600-610,723-733) */
 void msm_amd_set_quiet(int quiet);
 
+/* Where msm_amd_create builds the grid-kernel stencils K_l and K_L (the sl[] / sL of msmPeriodic.c:344-632, 99 % of
+ * the reference's run time): on the GPU (default; msm_stencil.hip) or on the host.  Same sums in the same order, so
+ * the two agree to a few 1e-16 relative.  Process-wide, read when a handle is created; the environment variable
+ * MSM_AMD_STENCILS=host|gpu overrides it.  msm_amd_hostplan_create always uses the host. */
+enum { MSM_AMD_STENCILS_HOST = 0, MSM_AMD_STENCILS_DEVICE = 1 };
+void msm_amd_set_stencil_backend(int where);
+int msm_amd_get_stencil_backend(void);
+
 /* what the acceleration output contains */
 enum {
     MSM_AMD_ACC_GRADIENT = 0, /* acc_i = sum_j q_j g0'(r) rhat + sum_m e_m grad phi_m(r_i)  (msmSimple.c:846,1330,1370) */
@@ -206,7 +214,7 @@ int msm_amd_plan_auto(int N, double Ax, double Ay, double Az, int p, int mu, dou
 
 typedef struct msm_amd_handle msm_amd_handle;
 
-/* Builds omega', all stencils (host, position independent) and allocates every device buffer.
+/* Builds omega', all stencils (position independent; see msm_amd_set_stencil_backend) and allocates every device buffer.
  * stream: a hipStream_t (NULL = the null stream) on which every later launch of this handle is queued. */
 int msm_amd_create(const msm_amd_plan_desc *plan, int device, void *stream, msm_amd_handle **out);
 /* Same, but every stage follows msmPeriodic.c's own index conventions (needs L=1, p=4, mu<=11); this is what

@@ -16,6 +16,7 @@ U_COUNT = 7
 ACC_GRADIENT, ACC_LITERAL, ACC_FORCE = 0, 1, 2
 EWALD_FULL, EWALD_LITERAL = 0, 1
 MODE_AUTO, MODE_LITERAL, MODE_SCALABLE = 0, 1, 2
+STENCILS_HOST, STENCILS_DEVICE = 0, 1
 GRID_Q, GRID_E, GRID_EFOUR = 0, 1, 2
 
 _dp = C.POINTER(C.c_double)
@@ -90,6 +91,8 @@ SIGNATURES = {
     # handle layer
     "msm_amd_set_mode": (None, [C.c_int]),
     "msm_amd_get_mode": (C.c_int, []),
+    "msm_amd_set_stencil_backend": (None, [C.c_int]),
+    "msm_amd_get_stencil_backend": (C.c_int, []),
     "msm_amd_set_quiet": (None, [C.c_int]),
     "msm_amd_plan_auto": (C.c_int, [C.c_int] + [C.c_double] * 3 + [C.c_int, C.c_int, C.c_double, C.c_int,
                                                                   C.POINTER(PlanDesc)]),

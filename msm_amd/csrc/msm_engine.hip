@@ -94,6 +94,17 @@ struct msm_amd_handle {
 static int g_mode = MSM_AMD_MODE_AUTO;
 static int g_quiet = 0;
 
+static int g_stencils = MSM_AMD_STENCILS_DEVICE;
+
+extern "C" void msm_amd_set_stencil_backend(int where) { g_stencils = where; }
+extern "C" int msm_amd_get_stencil_backend(void) {
+    // the environment overrides the process-wide setting (A/B runs of unmodified programs)
+    if (const char *e = getenv("MSM_AMD_STENCILS")) {
+        if (!strcmp(e, "host")) return MSM_AMD_STENCILS_HOST;
+        if (!strcmp(e, "gpu") || !strcmp(e, "device")) return MSM_AMD_STENCILS_DEVICE;
+    }
+    return g_stencils;
+}
 extern "C" void msm_amd_set_mode(int mode) { g_mode = mode; }
 extern "C" int msm_amd_get_mode(void) { return g_mode; }
 extern "C" void msm_amd_set_quiet(int quiet) { g_quiet = quiet; }
@@ -133,7 +144,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         delete h;
         return MSM_AMD_EINVAL;
     }
-    int rc = build_host_plan(h->hp);
+    int rc = build_host_plan(h->hp, msm_amd_get_stencil_backend() == MSM_AMD_STENCILS_DEVICE ? device_stencil_backend() : nullptr);
     if (rc) { delete h; return rc; }
     const msm_amd_plan_desc &d = h->hp.d;
     h->device = device;

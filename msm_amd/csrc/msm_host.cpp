@@ -185,10 +185,9 @@ static double level_kernel(const HostPlan &hp, int l, double r) {
 
 // K_l[n] = sum_k w'_|kx| w'_|ky| w'_|kz| sum_P g_l(|(n+k) h_l - A P|)   (msm/msmPeriodic.c:413-598,
 // msm/msmSimple.c:1016-1074) evaluated as: image-summed table over n+k, then three 1-D passes with w'.
-static void build_level(HostPlan &hp, int l) {
+void level_geometry(const HostPlan &hp, int l, LevelStencil &S, LevelGeom &G) {
     const int W = hp.d.mu + hp.d.p / 2;
-    LevelStencil &S = hp.K[l];
-    int ext[3], R[3];
+    G.W = W;
     for (int d = 0; d < 3; d++) {
         // msmPeriodic.c:435-453; in literal mode the z range is taken from Mx as the reference does (:437)
         const int Md = (hp.literal && d == 2) ? hp.Ml[l][0] : hp.Ml[l][d];
@@ -203,18 +202,26 @@ static void build_level(HostPlan &hp, int l) {
         }
         S.first[d] = lo;
         S.size[d] = hi - lo + 1;
-        ext[d] = S.size[d] + 2 * W;
+        G.ext[d] = S.size[d] + 2 * W;
     }
-    const double rcut = (l == hp.d.L - 1) ? std::fmax(std::ldexp(hp.d.a, l), 7.5 / hp.d.beta) : std::ldexp(hp.d.a, l + 1);
+    G.rcut = (l == hp.d.L - 1) ? std::fmax(std::ldexp(hp.d.a, l), 7.5 / hp.d.beta) : std::ldexp(hp.d.a, l + 1);
     for (int d = 0; d < 3; d++) {
         int jm = std::max(std::abs(S.first[d]), std::abs(S.first[d] + S.size[d] - 1)) + W;
-        R[d] = (int)std::ceil((jm * hp.hl[l][d] + rcut) / hp.d.A[d]);
-        if (hp.literal) R[d] = 5; // the reference sums images -5..5 whatever the cell (msmPeriodic.c:536-538)
+        G.R[d] = (int)std::ceil((jm * hp.hl[l][d] + G.rcut) / hp.d.A[d]);
+        if (hp.literal) G.R[d] = 5; // the reference sums images -5..5 whatever the cell (msmPeriodic.c:536-538)
+        G.amax[d] = std::max(std::abs(S.first[d] - W), std::abs(S.first[d] - W + G.ext[d] - 1));
     }
+}
+
+static void build_level(HostPlan &hp, int l) {
+    LevelStencil &S = hp.K[l];
+    LevelGeom geo;
+    level_geometry(hp, l, S, geo);
+    const int W = geo.W;
+    const int *ext = geo.ext, *R = geo.R, *amax = geo.amax;
+    const double rcut = geo.rcut;
     // The image sum is even in every coordinate (the images come in +- pairs), so it is evaluated once per
     // (|nx|, |ny|, |nz|) and copied to the other octants: an eighth of the kernel evaluations.
-    int amax[3];
-    for (int d = 0; d < 3; d++) amax[d] = std::max(std::abs(S.first[d] - W), std::abs(S.first[d] - W + ext[d] - 1));
     std::vector<double> T((size_t)(amax[0] + 1) * (amax[1] + 1) * (amax[2] + 1));
     for (int jz = 0; jz <= amax[2]; jz++)
         for (int jy = 0; jy <= amax[1]; jy++)
@@ -278,10 +285,9 @@ static void build_level(HostPlan &hp, int l) {
 // Fourier top level on the coarsest grid (msm/msmPeriodic.c:265-391, msm/msmSimple.c:1181-1246):
 // KL[n] = sum_{k != 0, |k_d| <= kmax} chi(k) (c_x c_y c_z)^2 cos(2 pi sum_d k_d n_d / ML_d), n in [0,ML)^3,
 // summed axis by axis with complex partial sums.
-static void build_top(HostPlan &hp) {
-    const int L = hp.d.L, kmax = hp.d.kmax, cn = 2 * kmax + 1, p2 = hp.d.p / 2;
+void top_prepare(HostPlan &hp) {
+    const int L = hp.d.L, kmax = hp.d.kmax, p2 = hp.d.p / 2;
     const int *ML = hp.Ml[L - 1];
-    const double vol = hp.d.A[0] * hp.d.A[1] * hp.d.A[2], beta = hp.d.beta;
     const double knots4[3] = {4.0 / 6.0, 1.0 / 6.0, 0.0}, knots6[3] = {66.0 / 120.0, 26.0 / 120.0, 1.0 / 120.0};
     const double *kn = (hp.d.p == 4) ? knots4 : knots6; // Phi at integer knots (msmPeriodic.c:71-72)
     for (int d = 0; d < 3; d++) {
@@ -292,6 +298,27 @@ static void build_top(HostPlan &hp) {
             hp.cvec[d][k] = 1.0 / c;
         }
     }
+    for (int d = 0; d < 3; d++) {
+        hp.KL.size[d] = ML[d];
+        hp.KL.first[d] = 0;
+    }
+}
+
+// e^{2 pi i t / M} for t in [0, M): k n is reduced mod M first, so every phase of the top-level sum is one of these
+void top_roots(int M, std::vector<double> &re_im) {
+    re_im.resize(2 * (size_t)M);
+    for (int t = 0; t < M; t++) {
+        const double th = 2 * PI * (double)t / (double)M;
+        re_im[2 * t] = std::cos(th);
+        re_im[2 * t + 1] = std::sin(th);
+    }
+}
+
+static void build_top(HostPlan &hp) {
+    top_prepare(hp);
+    const int L = hp.d.L, kmax = hp.d.kmax, cn = 2 * kmax + 1;
+    const int *ML = hp.Ml[L - 1];
+    const double vol = hp.d.A[0] * hp.d.A[1] * hp.d.A[2], beta = hp.d.beta;
     hp.chi.assign((size_t)cn * cn * cn, 0.0);
     hp.chisum = 0.0;
     std::vector<double> F((size_t)cn * cn * cn, 0.0);
@@ -312,11 +339,10 @@ static void build_top(HostPlan &hp) {
     // e^{2 pi i t / M} for t in [0, M), per axis: k n is reduced mod M first, so every phase is one of these
     std::vector<cd> roots[3];
     for (int d = 0; d < 3; d++) {
+        std::vector<double> ri;
+        top_roots(ML[d], ri);
         roots[d].resize(ML[d]);
-        for (int t = 0; t < ML[d]; t++) {
-            const double th = 2 * PI * (double)t / (double)ML[d];
-            roots[d][t] = cd(std::cos(th), std::sin(th));
-        }
+        for (int t = 0; t < ML[d]; t++) roots[d][t] = cd(ri[2 * t], ri[2 * t + 1]);
     }
     auto phase = [&](int k, int n, int d) {
         long t = ((long)k * n) % ML[d];
@@ -339,10 +365,6 @@ static void build_top(HostPlan &hp) {
                 S2[((size_t)kz * ML[1] + ny) * ML[0] + nx] = s;
             }
     hp.KL.v.assign((size_t)ML[0] * ML[1] * ML[2], 0.0);
-    for (int d = 0; d < 3; d++) {
-        hp.KL.size[d] = ML[d];
-        hp.KL.first[d] = 0;
-    }
     for (int nz = 0; nz < ML[2]; nz++)
         for (int ny = 0; ny < ML[1]; ny++)
             for (int nx = 0; nx < ML[0]; nx++) {
@@ -352,7 +374,7 @@ static void build_top(HostPlan &hp) {
             }
 }
 
-int build_host_plan(HostPlan &hp) {
+int build_host_plan(HostPlan &hp, const StencilBackend *be) {
     const msm_amd_plan_desc &d = hp.d;
     if (d.p != 4 && d.p != 6) { set_error("B-spline order p must be 4 or 6 (got %d)", d.p); return MSM_AMD_EINVAL; }
     if (d.L < 1 || d.L > LMAX) { set_error("number of grid levels L=%d out of range", d.L); return MSM_AMD_EINVAL; }
@@ -384,8 +406,17 @@ int build_host_plan(HostPlan &hp) {
     }
     two_scale(d.p, hp.J);
     hp.K.assign(d.L, LevelStencil());
-    for (int l = 0; l < d.L; l++) build_level(hp, l);
-    build_top(hp);
+    for (int l = 0; l < d.L; l++) {
+        if (!be) { build_level(hp, l); continue; }
+        const int rc = be->level(hp, l, be->ctx);
+        if (rc) return rc;
+    }
+    if (be) {
+        const int rc = be->top(hp, be->ctx);
+        if (rc) return rc;
+    } else {
+        build_top(hp);
+    }
     const double vol = d.A[0] * d.A[1] * d.A[2];
     hp.csr = PI / (d.beta * d.beta * vol); // msmPeriodic.c:294
     hp.gamma0 = gamma_eval(0.0, d.p);

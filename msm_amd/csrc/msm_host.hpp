@@ -42,8 +42,30 @@ double gamma_eval(double rho, int p);
 std::vector<double> compute_wprime(int p, int mu);
 void two_scale(int p, double J[4]);
 
-// fills Ml/hl/khat/wprime/J/K/KL/cvec/chi... from hp.d (+ hp.literal)
-int build_host_plan(HostPlan &hp);
+// Ranges of the stencil of level l (S.first, S.size) and of the image-summed kernel table it is built from: the table
+// spans ext = size + 2 W nodes per axis (W = mu + p/2), |node| <= amax, images -R..R, kernel support rcut.
+struct LevelGeom {
+    int W, ext[3], R[3], amax[3];
+    double rcut;
+};
+void level_geometry(const HostPlan &hp, int l, LevelStencil &S, LevelGeom &G);
+// c(k) per axis and the extent of the top-level stencil; roots of unity e^{2 pi i t / M} as (re, im) pairs
+void top_prepare(HostPlan &hp);
+void top_roots(int M, std::vector<double> &re_im);
+
+// An alternative implementation of the two stencil builders (the GPU one): level() fills hp.K[l], top() fills
+// hp.cvec, hp.chi, hp.chisum and hp.KL.
+struct StencilBackend {
+    int (*level)(HostPlan &hp, int l, void *ctx);
+    int (*top)(HostPlan &hp, void *ctx);
+    void *ctx;
+};
+
+// fills Ml/hl/khat/wprime/J/K/KL/cvec/chi... from hp.d (+ hp.literal); stencils by `be` when given, else on the host
+int build_host_plan(HostPlan &hp, const StencilBackend *be = nullptr);
+
+// stencil builders on the current HIP device (msm_stencil.hip)
+const StencilBackend *device_stencil_backend();
 
 void set_error(const char *fmt, ...);
 

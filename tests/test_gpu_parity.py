@@ -189,6 +189,83 @@ def test_pair_kernel_variants_agree(msm, torch):
         assert rel_rms(a2.cpu().numpy(), aw) < TOL
 
 
+STENCIL_PLANS = [
+    # N, A, p, mu, abar, L, literal
+    (512, (1.0, 1.0, 1.0), 4, 10, 4.0, 1, True),      # the reference's own regime: one level, images -5..5
+    (64, (1.0, 1.0, 1.0), 4, 10, 4.0, 1, True),
+    (3000, (1.0, 1.2, 0.9), 4, 10, 4.0, 2, False),
+    (3000, (1.0, 1.0, 1.0), 6, 4, 4.0, 2, False),
+    (100000, (1.0, 1.0, 1.0), 4, 10, 4.0, 3, False),  # 48 -> 24 -> 12
+    (1000000, (1.0, 1.0, 1.0), 6, 10, 4.0, 4, False), # the benchmark's plan: 96 -> 48 -> 24 -> 12
+    (200000, (1.0, 1.0, 1.0), 6, 10, 6.0, 0, False),  # wide stencils
+]
+
+
+@pytest.mark.parametrize("N,A,p,mu,abar,L,literal", STENCIL_PLANS)
+def test_device_stencils_match_host(msm, N, A, p, mu, abar, L, literal):
+    """Stencils generated on the GPU (msm_amd_create's default) against the host builder: every level and the
+    Fourier top level.  Same sums in the same order, so the two can differ only where the device library rounds
+    erf / erfc / exp differently (an ulp or two).  Below the coarsest level the kernel is a polynomial (IEEE
+    operations only): 1e-14 of the largest entry.  Top level: 1e-13 of the largest entry, which is the sum of the
+    absolute values of all terms.  Coarsest level: its table holds values up to T = 2 beta / sqrt(pi) + gamma(0) / a_L
+    (erf(beta r) / r near r = 0) and the three quasi-interpolation passes amplify a rounding difference by
+    (sum |omega'|)^3, so the bar is 8 ulp * T * (sum |omega'|)^3 - the uncertainty the host values carry themselves.
+    The evaluation's own 1e-12 parity tests run on the device-built stencils (the default)."""
+    from msm_amd import capi
+    lib = msm.load()
+    desc = msm.plan_auto(N, A, p, mu, abar, L)
+    host = msm.HostPlan(desc, literal=literal)
+    old = lib.msm_amd_get_stencil_backend()
+    try:
+        lib.msm_amd_set_stencil_backend(capi.STENCILS_DEVICE)
+        assert lib.msm_amd_get_stencil_backend() == capi.STENCILS_DEVICE
+        eng = msm.Engine(desc, literal=literal)
+    finally:
+        lib.msm_amd_set_stencil_backend(old)
+    for level in range(desc.L + 1):
+        kd, fd = eng.stencil(level)
+        kh, fh = host.stencil(level)
+        assert kd.shape == kh.shape and tuple(fd) == tuple(fh)
+        if level == desc.L - 1:
+            w = host.wprime()
+            amp = (abs(w[0]) + 2 * np.abs(w[1:]).sum()) ** 3
+            T = 2 * desc.beta / np.sqrt(np.pi) + host.scalars()["gamma0"] / (desc.a * 2 ** (desc.L - 1))
+            tol = 8 * np.finfo(float).eps * T * amp
+        else:
+            tol = (1e-13 if level == desc.L else 1e-14) * np.abs(kh).max()
+        assert np.abs(kd - kh).max() <= tol, "level %d of %d" % (level, desc.L)
+    eng.close()
+    host.close()
+
+
+@pytest.mark.parametrize("clustered", [False, True])
+def test_cluster_sorts_agree(msm, torch, clustered, monkeypatch):
+    """The two-level sort (column buckets ranked in LDS) and the sort with one global counter per fine bin store the
+    particles in the same slots: energies and accelerations are bitwise equal.  The clustered system puts a
+    third of the particles into a few columns, so that their buckets take the long-bucket path of the column pass."""
+    N, A = 60000, (1.0, 1.0, 1.0)
+    r, q = O.neutral_system(N, A, seed=5)
+    if clustered:
+        rng = np.random.default_rng(3)
+        k = N // 3
+        r[:k, 0] = 0.40 + 0.02 * rng.random(k)
+        r[:k, 1] = 0.70 + 0.02 * rng.random(k)
+    desc = msm.plan_auto(N, A, 6, 10, 4.0, 2)
+    rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
+    out = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MSM_AMD_SORT", mode)
+        eng = msm.Engine(desc)
+        en, acc = eng.eval(rd, qd)
+        out.append((np.array(en), acc.cpu().numpy().copy()))
+        eng.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    if not clustered:
+        sp = spec_for(desc)
+        ref = sp.eval(r, q)
+        assert rel_rms(out[0][1], ref["acc"]) < TOL
+
+
 @pytest.mark.parametrize("p,M", [(4, (28, 36, 26)), (6, (26, 24, 41)), (4, (24, 24, 24)), (6, (32, 40, 48))])
 def test_anterpolation_tiled(msm, torch, p, M):
     """LDS-tiled anterpolation (grids >= 24 per axis) against the oracle and against the gather kernel, on grid
