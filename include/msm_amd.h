@@ -119,6 +119,14 @@ double msmPeriodicRunner(double *r, double *q, double *f, int n, int p, int mu, 
  * computation of msm/nonperiodic.c:12-22 (which forces q = 1). */
 void direct(int N, double *r, double *q, double *ureal, double *freal);
 
+/* Open-boundary MSM on the GPU: *uappr = approximation of 1/2 sum_{i!=j} q_i q_j / r_ij, fappr[3N] = gradient of the
+ * potential at every particle (the sign and weighting of direct() above), grid spacing h, cutoff a, B-spline order p,
+ * quasi-interpolation width mu, smoothness s of the splitting (must equal p: the splitting of msmPeriodic.c:22-34).
+ * replaces msm3d(), declared at msm/msmLibrary.h:216 and defined nowhere in the reference: no reference output exists
+ * for it; it is checked against direct() within the method's accuracy and against the CPU oracle to 1e-12.
+ * Of the returned record N, L, mu, p, s, h, hx..hz, a, aL, the grid sizes and the potential_* fields are filled. */
+msm_stats msm3d(int N, double *r, double *q, int p, double h, double a, int mu, int s, double *uappr, double *fappr);
+
 /* Ewald sum of a periodic system on the GPU, host pointers: the total energy, with the three report lines on stderr.
  * replaces ewaldClassical(), msm/ewaldClassical.h:6, defined at msm/ewaldClassical.c:5-109 (real sum over the
  * particles as given, no images; reciprocal sum over kx^2+ky^2+kz^2 < cutoffFourier^2).  Returns NaN after
@@ -204,6 +212,13 @@ typedef struct msm_amd_plan_desc {
     double A[3];    /* periodic cell */
     double a;       /* short-range cutoff */
     double beta;    /* Ewald splitting of the top level */
+    /* Open boundaries (the non-periodic MSM declared as msm3d at msm/msmLibrary.h:216): the cell [origin, origin + A)
+     * is a padded box around the particles (msm_amd_plan_open sizes it), stencils have no image sums, the coarsest
+     * level applies gamma(r / a_l) / a_l over every node difference without wrap-around, and there is no Fourier
+     * level (kmax, beta unused), no csr and no self-image term.  0 = periodic (everything above). */
+    int open_boundary;
+    double origin[3];  /* position of the cell's corner: the engine works with r - origin (0 for periodic plans) */
+    double extent[3];  /* open plans: size of the particles' bounding box (sizes the sort's columns); 0 = the whole cell */
 } msm_amd_plan_desc;
 
 /* The reference's parameter choices (msmPeriodic.c:147-263) for L levels:
@@ -211,6 +226,13 @@ typedef struct msm_amd_plan_desc {
  * kmax=ceil|choosekmax|.  L<=0 selects min(allowed, wanted) of msmLibrary.c:46-62 capped so that the
  * coarsest grid has at least 8 nodes per axis. */
 int msm_amd_plan_auto(int N, double Ax, double Ay, double Az, int p, int mu, double abar, int L, msm_amd_plan_desc *out);
+
+/* Open-boundary plan for particles inside the box [lo, hi]: grid spacing h on every axis, cutoff a, L levels
+ * (L <= 0: as many as keep the coarsest grid at 8..32 nodes per axis).  The cell is the box plus the padding that
+ * keeps every level below the coarsest clear of the wrap-around, (p/2 + 1) coarsest-grid spacings of room for the
+ * spline supports, and at least 3 cutoffs per axis; M = A / h exactly, a multiple of 2^(L-1). */
+int msm_amd_plan_open(int N, const double lo[3], const double hi[3], int p, int mu, double h, double a, int L,
+                      msm_amd_plan_desc *out);
 
 typedef struct msm_amd_handle msm_amd_handle;
 

@@ -27,7 +27,8 @@ class PlanDesc(C.Structure):
     """struct msm_amd_plan_desc"""
     _fields_ = [("N", C.c_int), ("p", C.c_int), ("mu", C.c_int), ("L", C.c_int), ("kmax", C.c_int),
                 ("acc_convention", C.c_int), ("M", C.c_int * 3), ("zplane0", C.c_int), ("nzplanes", C.c_int),
-                ("n_owned", C.c_int), ("A", C.c_double * 3), ("a", C.c_double), ("beta", C.c_double)]
+                ("n_owned", C.c_int), ("A", C.c_double * 3), ("a", C.c_double), ("beta", C.c_double),
+                ("open_boundary", C.c_int), ("origin", C.c_double * 3), ("extent", C.c_double * 3)]
 
 
 class MsmStats(C.Structure):
@@ -123,6 +124,8 @@ SIGNATURES = {
     "msm_amd_op_prolong_add": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "msm_amd_op_convolve": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "direct": (None, [C.c_int, _dp, _dp, _dp, _dp]),
+    "msm3d": (MsmStats, [C.c_int, _dp, _dp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, _dp, _dp]),
+    "msm_amd_plan_open": (C.c_int, [C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(PlanDesc)]),
     "ewaldClassical": (C.c_double, [_dp, _dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
     "ewaldClassicalRunner": (None, [C.c_char_p, C.c_double, C.c_double, C.c_double]),
     "msm_amd_ewald_work_doubles": (C.c_longlong, [C.c_int, C.c_double, C.c_int]),

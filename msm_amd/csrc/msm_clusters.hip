@@ -33,7 +33,7 @@ __global__ void k_cl_count(const double *__restrict__ r, int N, ClusterGeom g, i
     double s[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        double t = r[3 * (size_t)i + d] * g.invA[d];
+        double t = (r[3 * (size_t)i + d] - g.origin[d]) * g.invA[d];
         s[d] = t - floor(t);
     }
     // grid-aligned columns are made of whole level-0 grid cells, so that a tile of cells is a set of columns
@@ -103,7 +103,7 @@ __global__ void k_cl_finalize(const double *__restrict__ r, const double *__rest
     double f[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        double t = r[3 * (size_t)i + d] * g.invA[d];
+        double t = (r[3 * (size_t)i + d] - g.origin[d]) * g.invA[d];
         f[d] = (t - floor(t)) * g.A[d];
     }
     order[dst] = i;
@@ -158,7 +158,7 @@ __device__ __forceinline__ int cl_bin_of(const double *__restrict__ r, int i, co
     double s[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        double t = r[3 * (size_t)i + d] * g.invA[d];
+        double t = (r[3 * (size_t)i + d] - g.origin[d]) * g.invA[d];
         s[d] = t - floor(t);
     }
     const int cx = g.kx ? min((int)(s[0] * (g.ncx * g.kx)), g.ncx * g.kx - 1) / g.kx : min((int)(s[0] * g.ncx), g.ncx - 1);
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void k_cs_scatter(const double *__restrict__ r
         double f[3];
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-            double t = r[3 * (size_t)i + d] * g.invA[d];
+            double t = (r[3 * (size_t)i + d] - g.origin[d]) * g.invA[d];
             f[d] = (t - floor(t)) * g.A[d];
         }
         bps[pos] = make_double4(f[0], f[1], f[2], q[i]);

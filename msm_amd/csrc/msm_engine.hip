@@ -170,6 +170,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
     h->ncell = h->small_box ? 1 : h->nc[0] * h->nc[1] * h->nc[2];
     for (int k = 0; k < 3; k++) {
         h->cellg.nb[k] = h->small_box ? 1 : h->nc[k];
+        h->cellg.origin[k] = h->gridg.origin[k] = d.origin[k];
         h->cellg.invA[k] = 1.0 / d.A[k];
         h->cellg.scale[k] = d.A[k];
         h->gridg.nb[k] = d.M[k];
@@ -229,6 +230,9 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
     {
         double occ = 1.0; // fraction of the cell a slab rank's particles (owned + halo) can occupy
         if (d.nzplanes < d.M[2]) occ = std::min(1.0, (d.nzplanes + 2.0 * (d.a / h->hp.hl[0][2] + d.p / 2)) / d.M[2]);
+        if (d.open_boundary) // the particles fill their bounding box, not the padded cell
+            for (int k = 0; k < 3; k++)
+                if (d.extent[k] > 0) occ *= std::min(1.0, std::max(d.extent[k], 0.05 * d.A[k]) / d.A[k]);
         const double vol = d.A[0] * d.A[1] * d.A[2] * occ;
         const double c = std::cbrt(CL_G * vol / std::max(N, 1));
         // One sort for everything when the level-0 grid allows it: columns of kx x ky whole grid cells (k a
@@ -285,7 +289,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
             cg.list_stride = (int)(2 * half);
         }
         double amax = 0;
-        for (int k = 0; k < 3; k++) { cg.A[k] = d.A[k]; cg.invA[k] = 1.0 / d.A[k]; amax = std::max(amax, d.A[k]); }
+        for (int k = 0; k < 3; k++) { cg.A[k] = d.A[k]; cg.invA[k] = 1.0 / d.A[k]; cg.origin[k] = d.origin[k]; amax = std::max(amax, d.A[k]); }
         cg.pitch[0] = d.A[0] / cg.ncx; cg.pitch[1] = d.A[1] / cg.ncy;
         cg.inv_pitch[0] = cg.ncx / d.A[0]; cg.inv_pitch[1] = cg.ncy / d.A[1];
         cg.dzf = d.A[2] / cg.nzf; cg.inv_dzf = cg.nzf / d.A[2];
@@ -339,7 +343,8 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
                 for (int sx = 0; sx < S.size[0]; sx++)
                     t[((size_t)sy * S.size[0] + sx) * S.size[2] + sz] = S.v[((size_t)sz * S.size[1] + sy) * S.size[0] + sx];
         HIPCHK(hipMemcpy(h->dKt[l], t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
-        if (!literal && S.size[0] == S.size[1] && S.size[1] == S.size[2] && S.size[0] > 23) {
+        const bool open_top = d.open_boundary && l == L - 1; // applied by k_conv_open from dK
+        if (!literal && !open_top && S.size[0] == S.size[1] && S.size[1] == S.size[2] && S.size[0] > 23) {
             // smallest padded width n * s over the cube sizes the kernel is built for; ties go to fewer cubes
             const int W = S.size[0];
             int bs = 0, bn = 0;
@@ -690,7 +695,10 @@ static void top_level(msm_amd_handle *h) {
     const int L = h->hp.d.L;
     const int *ML = h->hp.Ml[L - 1];
     const size_t nL = (size_t)ML[0] * ML[1] * ML[2];
-    if (top_fused(h)) {
+    if (h->hp.d.open_boundary) {
+        // every node of the coarsest grid against every node, no wrap-around; there is no Fourier level (efour stays 0)
+        launch_conv_open(h->stream, h->gq[L - 1], h->dK[L - 1], ML, h->ge[L - 1]);
+    } else if (top_fused(h)) {
         // the coarsest level's own convolution was left out of the coarse ranges: both in one pass
         launch_conv_small_pair(h->stream, h->gq[L - 1], h->dTsum, h->dTfour, ML, h->ge[L - 1], h->efour);
     } else if (h->hp.literal) {
@@ -725,7 +733,8 @@ extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
     } else {
         fine.push_back({0, 0, d.M[2]});
     }
-    const bool fused_top = top_fused(h);
+    // the coarsest level's convolution belongs to top_level() when it is fused with the Fourier level or open
+    const bool fused_top = top_fused(h) || d.open_boundary;
     for (int l = 1; l < L; l++)
         if (!(fused_top && l == L - 1)) coarse.push_back({l, 0, h->hp.Ml[l][2]});
     if (fused_top && L == 1) fine.clear();
@@ -1075,6 +1084,8 @@ extern "C" int msm_amd_op_convolve(msm_amd_handle *h, int l, const double *d_q, 
     if (l == h->hp.d.L) {
         const int *ML = h->hp.Ml[l - 1];
         conv_untiled(h, d_q, h->dKL, ML, h->hp.KL.size, h->hp.KL.first, d_e, 0, ML[2]);
+    } else if (h->hp.d.open_boundary && l == h->hp.d.L - 1) {
+        launch_conv_open(h->stream, d_q, h->dK[l], h->hp.Ml[l], d_e);
     } else {
         convolve_level(h, l, d_q, d_e, 0, h->hp.Ml[l][2]);
     }
@@ -1229,6 +1240,57 @@ extern "C" msm_stats msmperiodic(int N, double *r, double *q, int p, double abar
         S.netcharge = qs;
         S.netgridcharge[0] = gs;
     }
+    msm_amd_destroy(h);
+    S.cputime_total = now_s() - t_total;
+    return S;
+}
+
+// Open-boundary MSM (msm3d, declared at msm/msmLibrary.h:216 and defined nowhere in the reference): plan around the
+// particles' bounding box, one evaluation through the handle layer, energies into the result record.
+extern "C" msm_stats msm3d(int N, double *r, double *q, int p, double hgrid, double a, int mu, int s, double *uappr,
+                           double *fappr) {
+    msm_stats S;
+    memset(&S, 0, sizeof(S));
+    const double t_total = now_s();
+    S.N = N; S.p = p; S.mu = mu; S.s = s;
+    if (N < 1 || !r || !q || !fappr) { fprintf(stderr, "msm3d: bad arguments\n"); return S; }
+    if ((p != 4 && p != 6) || s != p) { // the splitting gamma has as many terms as the spline has order (msmPeriodic.c:22-34)
+        fprintf(stderr, "msm3d: p must be 4 or 6 and s must equal p\n");
+        return S;
+    }
+    double lo[3] = {r[0], r[1], r[2]}, hi[3] = {r[0], r[1], r[2]};
+    for (int i = 1; i < N; i++)
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(lo[k], r[3 * (size_t)i + k]);
+            hi[k] = std::max(hi[k], r[3 * (size_t)i + k]);
+        }
+    msm_amd_plan_desc d;
+    int rc = msm_amd_plan_open(N, lo, hi, p, mu, hgrid, a, 0, &d);
+    if (rc) { fprintf(stderr, "msm3d: %s\n", msm_amd_last_error()); return S; }
+    double t0 = now_s();
+    msm_amd_handle *h = nullptr;
+    rc = create_impl(&d, false, 0, nullptr, &h);
+    if (rc) { fprintf(stderr, "msm3d: %s\n", msm_amd_last_error()); return S; }
+    S.cputime_stencill = now_s() - t0;
+    double en[MSM_AMD_U_COUNT];
+    rc = msm_amd_eval_host(h, r, q, fappr, en);
+    if (rc) { fprintf(stderr, "msm3d: %s\n", msm_amd_last_error()); msm_amd_destroy(h); return S; }
+    const int L = d.L;
+    S.L = L; S.h = hgrid; S.hx = h->hp.hl[0][0]; S.hy = h->hp.hl[0][1]; S.hz = h->hp.hl[0][2];
+    S.a = a; S.aL = std::ldexp(a, L - 1); S.alpha = a / hgrid;
+    S.rminx = lo[0]; S.rminy = lo[1]; S.rminz = lo[2]; S.rmaxx = hi[0]; S.rmaxy = hi[1]; S.rmaxz = hi[2];
+    S.volume = d.A[0] * d.A[1] * d.A[2];
+    S.Mx = d.M[0]; S.My = d.M[1]; S.Mz = d.M[2];
+    for (int l = 0; l < L && l < LMAX; l++) { S.Mlx[l] = h->hp.Ml[l][0]; S.Mly[l] = h->hp.Ml[l][1]; S.Mlz[l] = h->hp.Ml[l][2]; }
+    S.MLx = h->hp.Ml[L - 1][0]; S.MLy = h->hp.Ml[L - 1][1]; S.MLz = h->hp.Ml[L - 1][2];
+    S.potential_short_real = en[MSM_AMD_U_SHORT_REAL];
+    S.potential_short_total = en[0] + en[1] + en[2];
+    S.potential_long_real = en[MSM_AMD_U_LONG_REAL];
+    S.potential_long_self = en[MSM_AMD_U_LONG_SELF];
+    S.potential_long_total = en[MSM_AMD_U_LONG_FOUR] + en[MSM_AMD_U_LONG_REAL] + en[MSM_AMD_U_LONG_SELF];
+    S.potential_total = en[MSM_AMD_U_TOTAL];
+    if (uappr) *uappr = S.potential_total;
+    { double qs = 0.0; for (int i = 0; i < N; i++) qs += q[i]; S.netcharge = qs; }
     msm_amd_destroy(h);
     S.cputime_total = now_s() - t_total;
     return S;

@@ -174,6 +174,7 @@ std::vector<double> compute_wprime(int p, int mu) {
 static double level_kernel(const HostPlan &hp, int l, double r) {
     const int p = hp.d.p, L = hp.d.L;
     const double al = std::ldexp(hp.d.a, l), al1 = std::ldexp(hp.d.a, l + 1), beta = hp.d.beta;
+    if (l == L - 1 && hp.d.open_boundary) return gamma_eval(r / al, p) / al; // the whole remainder, 1 / r beyond a_l
     if (l == L - 1) {
         if (r >= al) return std::erfc(beta * r) / r;
         const double lr = (r < DBL_EPSILON) ? 2.0 * beta / std::sqrt(PI) : std::erf(beta * r) / r;
@@ -200,15 +201,19 @@ void level_geometry(const HostPlan &hp, int l, LevelStencil &S, LevelGeom &G) {
             lo = -hp.khat[d] + 1;
             hi = hp.khat[d] - 1;
         }
+        // open boundaries: the coarsest level couples every pair of nodes, differences -(M-1)..M-1
+        if (hp.d.open_boundary && l == hp.d.L - 1) { lo = -(hp.Ml[l][d] - 1); hi = hp.Ml[l][d] - 1; }
         S.first[d] = lo;
         S.size[d] = hi - lo + 1;
         G.ext[d] = S.size[d] + 2 * W;
     }
     G.rcut = (l == hp.d.L - 1) ? std::fmax(std::ldexp(hp.d.a, l), 7.5 / hp.d.beta) : std::ldexp(hp.d.a, l + 1);
+    if (hp.d.open_boundary && l == hp.d.L - 1) G.rcut = 1e300;
     for (int d = 0; d < 3; d++) {
         int jm = std::max(std::abs(S.first[d]), std::abs(S.first[d] + S.size[d] - 1)) + W;
         G.R[d] = (int)std::ceil((jm * hp.hl[l][d] + G.rcut) / hp.d.A[d]);
         if (hp.literal) G.R[d] = 5; // the reference sums images -5..5 whatever the cell (msmPeriodic.c:536-538)
+        if (hp.d.open_boundary) G.R[d] = 0;
         G.amax[d] = std::max(std::abs(S.first[d] - W), std::abs(S.first[d] - W + G.ext[d] - 1));
     }
 }
@@ -314,7 +319,18 @@ void top_roots(int M, std::vector<double> &re_im) {
     }
 }
 
+// open boundaries: no Fourier level
+void top_open(HostPlan &hp) {
+    top_prepare(hp);
+    const int cn = 2 * hp.d.kmax + 1;
+    const int *ML = hp.Ml[hp.d.L - 1];
+    hp.chi.assign((size_t)cn * cn * cn, 0.0);
+    hp.chisum = 0.0;
+    hp.KL.v.assign((size_t)ML[0] * ML[1] * ML[2], 0.0);
+}
+
 static void build_top(HostPlan &hp) {
+    if (hp.d.open_boundary) { top_open(hp); return; }
     top_prepare(hp);
     const int L = hp.d.L, kmax = hp.d.kmax, cn = 2 * kmax + 1;
     const int *ML = hp.Ml[L - 1];
@@ -386,6 +402,10 @@ int build_host_plan(HostPlan &hp, const StencilBackend *be) {
             return MSM_AMD_EINVAL;
         }
     }
+    if (d.open_boundary && (hp.literal || d.nzplanes != d.M[2])) {
+        set_error("open-boundary plans have no literal mode and no slab decomposition");
+        return MSM_AMD_EINVAL;
+    }
     if (hp.literal && (d.L != 1 || d.p != 4 || d.mu + d.p / 2 > 13)) {
         set_error("literal mode needs L=1, p=4, mu<=11 (msmPeriodic.c:100-104, msmLibrary.c:64-66, msmLibrary.h:14)");
         return MSM_AMD_EINVAL;
@@ -418,12 +438,13 @@ int build_host_plan(HostPlan &hp, const StencilBackend *be) {
         build_top(hp);
     }
     const double vol = d.A[0] * d.A[1] * d.A[2];
-    hp.csr = PI / (d.beta * d.beta * vol); // msmPeriodic.c:294
+    hp.csr = d.open_boundary ? 0.0 : PI / (d.beta * d.beta * vol); // msmPeriodic.c:294
     hp.gamma0 = gamma_eval(0.0, d.p);
     // sum over the images of a particle with itself inside the cutoff (msmLibrary.c:141-167 with i == j)
     hp.self_image_sum = 0.0;
     {
-        const int Rx = (int)(d.a / d.A[0]), Ry = (int)(d.a / d.A[1]), Rz = (int)(d.a / d.A[2]);
+        const int Rx = d.open_boundary ? 0 : (int)(d.a / d.A[0]), Ry = d.open_boundary ? 0 : (int)(d.a / d.A[1]),
+                  Rz = d.open_boundary ? 0 : (int)(d.a / d.A[2]);
         for (int px = -Rx; px <= Rx; px++)
             for (int py = -Ry; py <= Ry; py++)
                 for (int pz = -Rz; pz <= Rz; pz++) {
@@ -593,6 +614,54 @@ int msm_amd_plan_auto(int N, double Ax, double Ay, double Az, int p, int mu, dou
     o->zplane0 = 0;
     o->nzplanes = o->M[2];
     o->acc_convention = MSM_AMD_ACC_GRADIENT;
+    return MSM_AMD_OK;
+}
+
+int msm_amd_plan_open(int N, const double lo[3], const double hi[3], int p, int mu, double h, double a, int L,
+                      msm_amd_plan_desc *o) {
+    if (!o || !lo || !hi || N < 1 || !(h > 0) || !(a > 0) || (p != 4 && p != 6)) {
+        msm::set_error("msm_amd_plan_open: bad arguments");
+        return MSM_AMD_EINVAL;
+    }
+    double E[3], Emax = 0.0;
+    for (int k = 0; k < 3; k++) {
+        E[k] = hi[k] - lo[k];
+        if (!(E[k] >= 0)) { msm::set_error("msm_amd_plan_open: hi < lo"); return MSM_AMD_EINVAL; }
+        Emax = std::max(Emax, E[k]);
+    }
+    // room the cell needs beyond the particles' box with L levels (hc = coarsest spacing):
+    //   coarsest level: grid charges and needed potentials reach (p/2) hc beyond the particles, plus a node of slack;
+    //   level L-2: they reach (p/2) h_{L-2} and its stencil 2^(L-1) a, which must not meet across the wrap;
+    //   the pair sum wants at least three cutoffs per axis.
+    auto room = [&](int levels, double Ek) {
+        const double hc = std::ldexp(h, levels - 1);
+        double need = (p + 2) * hc;
+        if (levels >= 2) need = std::max(need, (p / 2) * hc + std::ldexp(a, levels - 1) + 2 * h);
+        return std::max(need, 3.05 * a - Ek);
+    };
+    if (L <= 0) { // deepest hierarchy whose coarsest grid still has 8 nodes on the longest axis, at most 32 on it
+        L = 1;
+        while (L < LMAX && (Emax + room(L, Emax)) / std::ldexp(h, L - 1) > 32.0) L++;
+        while (L > 1 && (Emax + room(L, Emax)) / std::ldexp(h, L - 1) < 8.0) L--;
+    }
+    if (L > LMAX) { msm::set_error("msm_amd_plan_open: L=%d out of range", L); return MSM_AMD_EINVAL; }
+    memset(o, 0, sizeof(*o));
+    o->N = N; o->p = p; o->mu = mu; o->L = L; o->kmax = 0;
+    o->a = a; o->beta = 1.0;
+    o->open_boundary = 1;
+    o->acc_convention = MSM_AMD_ACC_GRADIENT;
+    const int mult = 1 << (L - 1);
+    for (int k = 0; k < 3; k++) {
+        long M = (long)std::ceil((E[k] + room(L, E[k])) / h);
+        M = (M + mult - 1) / mult * mult;
+        if (M > 4096) { msm::set_error("msm_amd_plan_open: grid of %ld nodes per axis", M); return MSM_AMD_ERANGE; }
+        o->M[k] = (int)M;
+        o->A[k] = M * h;
+        o->extent[k] = E[k];
+        o->origin[k] = lo[k] - 0.5 * (o->A[k] - E[k]); // particles in the middle of the cell
+    }
+    o->zplane0 = 0;
+    o->nzplanes = o->M[2];
     return MSM_AMD_OK;
 }
 

@@ -51,6 +51,7 @@ struct LevelGeom {
 void level_geometry(const HostPlan &hp, int l, LevelStencil &S, LevelGeom &G);
 // c(k) per axis and the extent of the top-level stencil; roots of unity e^{2 pi i t / M} as (re, im) pairs
 void top_prepare(HostPlan &hp);
+void top_open(HostPlan &hp); // open boundaries: empty Fourier level
 void top_roots(int M, std::vector<double> &re_im);
 
 // An alternative implementation of the two stencil builders (the GPU one): level() fills hp.K[l], top() fills

@@ -23,7 +23,7 @@ namespace msm {
 __device__ __forceinline__ void frac_coords(const double *__restrict__ r, int i, const BinGeom &g, double s[3]) {
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        double t = r[3 * (size_t)i + d] * g.invA[d];
+        double t = (r[3 * (size_t)i + d] - g.origin[d]) * g.invA[d];
         t -= floor(t);
         s[d] = t;
     }
@@ -1121,6 +1121,43 @@ __global__ __launch_bounds__(256) void k_conv_direct(const double *__restrict__ 
     }
     const size_t o = ((size_t)mz * My + my) * Mx + mx;
     e[o] = c.accumulate ? e[o] + s : s;
+}
+
+// Open boundaries, coarsest level: every node against every node, no wrap-around.  A workgroup owns 64 output nodes
+// (one per lane) and its 16 waves share the input rows (nz, ny) between them; the 16 partial sums of a node are added in
+// wave order.  The charge of the inner loop is the same address for the whole wave, the stencil entries of neighbouring
+// lanes are neighbours in memory.
+#define CONV_OPEN_SLICES 16
+__global__ __launch_bounds__(64 * CONV_OPEN_SLICES) void k_conv_open(const double *__restrict__ q, const double *__restrict__ K,
+                                                                     double *__restrict__ e, int Mx, int My, int Mz) {
+    __shared__ double part[CONV_OPEN_SLICES][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int n = Mx * My * Mz, idx = min(blockIdx.x * 64 + lane, n - 1); // lanes past the end repeat the last node
+    const int mx = idx % Mx, my = (idx / Mx) % My, mz = idx / (Mx * My);
+    const int sx = 2 * Mx - 1, sy = 2 * My - 1;
+    const int rows = My * Mz, per = (rows + CONV_OPEN_SLICES - 1) / CONV_OPEN_SLICES;
+    const int r0 = min(rows, slice * per), r1 = min(rows, r0 + per);
+    double s = 0.0;
+    for (int row = r0; row < r1; row++) {
+        const int nz = row / My, ny = row - nz * My;
+        const double *qrow = q + (size_t)row * Mx;
+        const double *krow = K + ((size_t)(mz - nz + Mz - 1) * sy + (my - ny + My - 1)) * sx + mx + Mx - 1;
+#pragma unroll 8
+        for (int nx = 0; nx < Mx; nx++) s = fma(krow[-nx], qrow[nx], s);
+    }
+    part[slice][lane] = s;
+    __syncthreads();
+    if (slice == 0 && blockIdx.x * 64 + lane < n) {
+        double t = part[0][lane];
+#pragma unroll
+        for (int k = 1; k < CONV_OPEN_SLICES; k++) t += part[k][lane];
+        e[idx] = t;
+    }
+}
+
+void launch_conv_open(hipStream_t st, const double *q, const double *K, const int M[3], double *e) {
+    const long n = (long)M[0] * M[1] * M[2];
+    hipLaunchKernelGGL(k_conv_open, dim3((unsigned)((n + 63) / 64)), dim3(64 * CONV_OPEN_SLICES), 0, st, q, K, e, M[0], M[1], M[2]);
 }
 
 void launch_conv_direct(hipStream_t st, const double *q, const double *K, const int M[3], const int ksize[3],

@@ -13,6 +13,7 @@ struct BinGeom {
     int nbins;
     double invA[3];
     double scale[3];
+    double origin[3]; // corner of the cell (0 for periodic plans)
 };
 
 struct PairParams {
@@ -83,6 +84,7 @@ struct ClusterGeom {
     double inv_dzf, dzf; // fine bins per unit length in z
     double far;          // coordinate given to padding slots
     float a2_wide;       // cutoff^2 widened to cover single-precision rounding in the box tests
+    double origin[3];    // corner of the cell (0 for periodic plans): positions enter as r - origin
     int sort_blocks;     // workgroups of the two-level sort (0: the sort with one counter per fine bin is used)
 };
 struct ClusterBuffers {
@@ -170,6 +172,9 @@ bool launch_conv_multi(hipStream_t st, ConvBatch &B);
 void launch_conv_small_pair(hipStream_t st, const double *q, const double *Ta, const double *Tb, const int M[3], double *ea,
                             double *eb);
 // ---- grid convolution: e[m] = sum_s K[s] q[(m - (first + s)) mod M] for planes [z0, z0+nz) ----
+// open boundaries: e[m] = sum_n K[m - n] q[n] over the nodes of the grid without wrap-around; K holds every node
+// difference -(M-1)..M-1, x fastest
+void launch_conv_open(hipStream_t st, const double *q, const double *K, const int M[3], double *e);
 void launch_conv_direct(hipStream_t st, const double *q, const double *K, const int M[3], const int ksize[3],
                         const int kfirst[3], double *e, int z0, int nz, int accumulate);
 // one wave per output node (small grids with stencils spanning the period)

@@ -25,6 +25,7 @@ namespace {
 
 struct StLevel {
     int p, last;            // spline order; 1 on the coarsest level (kernel = splitting remainder - Ewald long-range part)
+    int open;               // open boundaries: the coarsest level keeps the whole remainder gamma(r / a_l) / a_l
     double al, al1;         // cutoffs of this level and the next, 2^l a and 2^(l+1) a
     double beta, lr0;       // Ewald splitting parameter; limit of erf(beta r)/r at r = 0
     double rcut;
@@ -43,6 +44,7 @@ __device__ double st_gamma(double rho, const StLevel &c) {
 }
 
 __device__ double st_kernel(const StLevel &c, double r) {
+    if (c.last && c.open) return st_gamma(r / c.al, c) / c.al;
     if (c.last) {
         if (r >= c.al) return erfc(c.beta * r) / r;
         const double lr = (r < DBL_EPSILON) ? c.lr0 : erf(c.beta * r) / r;
@@ -162,6 +164,7 @@ int device_level(HostPlan &hp, int l, void *) {
     StLevel c;
     c.p = hp.d.p;
     c.last = (l == hp.d.L - 1) ? 1 : 0;
+    c.open = hp.d.open_boundary ? 1 : 0;
     c.al = std::ldexp(hp.d.a, l);
     c.al1 = std::ldexp(hp.d.a, l + 1);
     c.beta = hp.d.beta;
@@ -196,6 +199,7 @@ int device_level(HostPlan &hp, int l, void *) {
 }
 
 int device_top(HostPlan &hp, void *) {
+    if (hp.d.open_boundary) { top_open(hp); return MSM_AMD_OK; }
     top_prepare(hp);
     const int L = hp.d.L, kmax = hp.d.kmax, cn = 2 * kmax + 1;
     const int *ML = hp.Ml[L - 1];

@@ -24,6 +24,16 @@ def plan_auto(N, A, p=4, mu=10, abar=4.0, L=0):
     return d
 
 
+def plan_open(N, lo, hi, p, mu, h, a, L=0):
+    """Open-boundary plan (msm_amd_plan_open) for particles inside the box [lo, hi]."""
+    d = PlanDesc()
+    lo3 = (C.c_double * 3)(*[float(x) for x in lo])
+    hi3 = (C.c_double * 3)(*[float(x) for x in hi])
+    check(load().msm_amd_plan_open(int(N), lo3, hi3, int(p), int(mu), float(h), float(a), int(L), C.byref(d)),
+          "msm_amd_plan_open")
+    return d
+
+
 def plan_explicit(N, A, M, p, mu, L, a, beta, kmax, acc_convention=capi.ACC_GRADIENT):
     d = PlanDesc()
     d.N, d.p, d.mu, d.L, d.kmax, d.acc_convention = int(N), int(p), int(mu), int(L), int(kmax), int(acc_convention)
@@ -264,6 +274,21 @@ def direct(r, q):
     u = C.c_double(0.0)
     lib.direct(n, r.ctypes.data_as(_dp), q.ctypes.data_as(_dp), C.byref(u), f.ctypes.data_as(_dp))
     return u.value, f
+
+
+def msm3d(r, q, p, h, a, mu, s=None):
+    """msm3d() of msm/msmLibrary.h:216 through the C ABI: open-boundary MSM energy and potential gradient.
+
+    Returns (u: float, acc: (N,3) array, stats)."""
+    lib = load()
+    r = np.ascontiguousarray(r, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    n = q.shape[0]
+    f = np.zeros((n, 3))
+    u = C.c_double(0.0)
+    st = lib.msm3d(n, r.ctypes.data_as(_dp), q.ctypes.data_as(_dp), int(p), float(h), float(a), int(mu),
+                   int(p if s is None else s), C.byref(u), f.ctypes.data_as(_dp))
+    return u.value, f, st
 
 
 def ewaldClassical(r, q, A, alpha, cutoffDirect, cutoffFourier):

@@ -83,6 +83,8 @@ int or_spec_auto_params(int N, double Ax, double Ay, double Az, int p, int mu, d
 typedef struct or_spec_plan or_spec_plan;
 /* image range of the stencil sums: 0 = complete (default), R = -R..R only (msmPeriodic.c:536-538 uses 5) */
 void or_spec_set_image_range(int R);
+/* on != 0: plans created from now on are open-boundary plans (msm3d of msm/msmLibrary.h:216; see msm_spec.c) */
+void or_spec_set_open_boundary(int on);
 or_spec_plan *or_spec_plan_create(const or_spec_params *prm);
 void or_spec_plan_destroy(or_spec_plan *pl);
 /* stencil of grid level l: values (x fastest), extents and first offset per dimension */

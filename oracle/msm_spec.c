@@ -32,12 +32,24 @@ struct or_spec_plan {
     int Ksize[OR_MAXL][3], Kfirst[OR_MAXL][3];
     double *KL;
     double *qg[OR_MAXL], *eg[OR_MAXL], *efour;
+    int open;                 /* open-boundary plan (see or_spec_set_open_boundary) */
 };
 
 /* 0: sum every periodic image that can contribute; R > 0: images -R..R only, as the reference's
  * hard-wired -5..5 (msmPeriodic.c:536-538) */
 static int g_image_range = 0;
 void or_spec_set_image_range(int R) { g_image_range = R; }
+
+/* Open boundaries (the non-periodic MSM that msm/msmLibrary.h:216 declares as msm3d and no file of the reference
+ * defines; PARITY UNPINNED by any reference output, pinned by the direct sum of msm/nonperiodic.c:12-22 within the
+ * method's accuracy).  Same pipeline on the same periodic arrays, with the caller's cell A a padded box around the
+ * particles, wide enough that nothing below the coarsest level reaches across the wrap, and:
+ *   - no image sums in any stencil, no Fourier level, no csr / self-image terms;
+ *   - coarsest level: kernel gamma(r / a_l) / a_l at every distance (= 1 / r beyond a_l), stencil over every node
+ *     difference -(M-1)..M-1, applied without wrap-around (node index m is position m h and nothing else).
+ * Read when a plan is created. */
+static int g_open = 0;
+void or_spec_set_open_boundary(int on) { g_open = on; }
 
 static double now_s(void) {
 #ifdef _OPENMP
@@ -75,6 +87,7 @@ int or_spec_auto_params(int N, double Ax, double Ay, double Az, int p, int mu, d
 static double level_kernel(const or_spec_plan *pl, int l, double r) {
     int p = pl->prm.p, L = pl->prm.L;
     double al = ldexp(pl->prm.a, l), al1 = ldexp(pl->prm.a, l + 1);
+    if (l == L - 1 && pl->open) return or_gamma(r / al, p) / al;
     if (l == L - 1) {
         if (r >= al) return erfc(pl->prm.beta * r) / r;
         if (r < DBL_EPSILON) return or_gamma(0.0, p) / al - 2.0 * pl->prm.beta / sqrt(OR_PI);
@@ -93,15 +106,17 @@ static void build_level_stencil(or_spec_plan *pl, int l) {
         double half = pl->Ml[l][d] / 2.0;
         if (pl->khat[d] > half) { lo[d] = (int)floor(-half) + 1; hi[d] = (int)floor(half); }
         else { lo[d] = -pl->khat[d] + 1; hi[d] = pl->khat[d] - 1; }
+        if (pl->open && l == P->L - 1) { lo[d] = -(pl->Ml[l][d] - 1); hi[d] = pl->Ml[l][d] - 1; }
         pl->Kfirst[l][d] = lo[d];
         pl->Ksize[l][d] = hi[d] - lo[d] + 1;
         ext[d] = pl->Ksize[l][d] + 2 * W;
     }
     rcut = (l == P->L - 1) ? fmax(ldexp(P->a, l), 7.5 / P->beta) : ldexp(P->a, l + 1);
+    if (pl->open && l == P->L - 1) rcut = 1e300;
     for (d = 0; d < 3; d++) {
         int jmax = (abs(lo[d]) > abs(hi[d]) ? abs(lo[d]) : abs(hi[d])) + W;
-        R[d] = (int)ceil((jmax * pl->hl[l][d] + rcut) / P->A[d]);
-        if (g_image_range > 0) R[d] = g_image_range;
+        R[d] = pl->open ? 0 : (int)ceil((jmax * pl->hl[l][d] + rcut) / P->A[d]);
+        if (g_image_range > 0 && !pl->open) R[d] = g_image_range;
     }
     G = (double *)malloc(sizeof(double) * (size_t)ext[0] * ext[1] * ext[2]);
 #pragma omp parallel for collapse(2) private(nx, px, py, pz)
@@ -151,6 +166,7 @@ static void build_top_stencil(or_spec_plan *pl) {
     int kmax = P->kmax, cn = 2 * kmax + 1, k, m, d, kx, ky, kz, nx, ny, nz;
     double phik[3] = {0, 0, 0}, vol = P->A[0] * P->A[1] * P->A[2];
     double *cv[3], *chi;
+    if (pl->open) { pl->KL = (double *)calloc((size_t)ML[0] * ML[1] * ML[2], sizeof(double)); return; }
     or_phi_at_knots(P->p, phik);
     for (d = 0; d < 3; d++) {
         cv[d] = (double *)malloc(sizeof(double) * (kmax + 1));
@@ -195,6 +211,7 @@ or_spec_plan *or_spec_plan_create(const or_spec_params *prm) {
         if (prm->M[d] < 1 || (prm->M[d] % (1 << (prm->L - 1))) != 0) return NULL;
     pl = (or_spec_plan *)calloc(1, sizeof(*pl));
     pl->prm = *prm;
+    pl->open = g_open;
 #ifdef _OPENMP
     if (prm->nthreads > 0) omp_set_num_threads(prm->nthreads);
 #endif
@@ -474,7 +491,29 @@ static void conv_periodic(const int M[3], const double *K, const int ks[3], cons
         }
 }
 
+/* e_m = sum_n K_{m-n} q_n over the nodes of the grid, no wrap-around; K holds every difference -(M-1)..M-1 */
+static void conv_open(const int M[3], const double *K, const double *q, double *e) {
+    int mz, my;
+    const int sx = 2 * M[0] - 1, sy = 2 * M[1] - 1;
+#pragma omp parallel for collapse(2)
+    for (mz = 0; mz < M[2]; mz++)
+        for (my = 0; my < M[1]; my++) {
+            int mx, nz, ny, nx;
+            for (mx = 0; mx < M[0]; mx++) {
+                double s = 0.0;
+                for (nz = 0; nz < M[2]; nz++)
+                    for (ny = 0; ny < M[1]; ny++) {
+                        const double *qrow = q + ((size_t)nz * M[1] + ny) * M[0];
+                        const double *krow = K + ((size_t)(mz - nz + M[2] - 1) * sy + (my - ny + M[1] - 1)) * sx + mx + M[0] - 1;
+                        for (nx = 0; nx < M[0]; nx++) s += krow[-nx] * qrow[nx];
+                    }
+                e[((size_t)mz * M[1] + my) * M[0] + mx] = s;
+            }
+        }
+}
+
 void or_spec_convolve(const or_spec_plan *pl, int l, const double *q, double *e) {
+    if (pl->open && l == pl->prm.L - 1) { conv_open(pl->Ml[l], pl->K[l], q, e); return; }
     conv_periodic(pl->Ml[l], pl->K[l], pl->Ksize[l], pl->Kfirst[l], q, e);
 }
 void or_spec_convolve_top(const or_spec_plan *pl, const double *q, double *e) {
@@ -551,7 +590,7 @@ int or_spec_eval(or_spec_plan *pl, const double *r, const double *q, double *acc
             }
     en[OR_U_SHORT_REAL] = ureal;
     en[OR_U_SHORT_SELF] = 0.5 * qs2 * psum;
-    en[OR_U_SHORT_CSR] = -0.5 * qs * qs * OR_PI / (P->beta * P->beta * P->A[0] * P->A[1] * P->A[2]);
+    en[OR_U_SHORT_CSR] = pl->open ? 0.0 : -0.5 * qs * qs * OR_PI / (P->beta * P->beta * P->A[0] * P->A[1] * P->A[2]);
     en[OR_U_LONG_FOUR] = ufour;
     en[OR_U_LONG_REAL] = utot_grid - ufour;
     en[OR_U_LONG_SELF] = -0.5 * qs2 * or_gamma(0.0, P->p) / a;

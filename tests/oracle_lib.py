@@ -98,6 +98,8 @@ def lib():
     L.or_spec_plan_create.argtypes = [C.POINTER(SpecParams)]
     L.or_spec_set_image_range.restype = None
     L.or_spec_set_image_range.argtypes = [C.c_int]
+    L.or_spec_set_open_boundary.restype = None
+    L.or_spec_set_open_boundary.argtypes = [C.c_int]
     L.or_spec_plan_destroy.restype = None
     L.or_spec_plan_destroy.argtypes = [C.c_void_p]
     L.or_spec_stencil.restype = _dp
@@ -182,9 +184,13 @@ def literal_run(r, q, p, abar, mu, A):
 class SpecPlan:
     """Specification engine plan (see oracle/msm_spec.c)."""
 
-    def __init__(self, prm):
+    def __init__(self, prm, open_boundary=False):
         self.prm = prm
-        self.h = lib().or_spec_plan_create(C.byref(prm))
+        lib().or_spec_set_open_boundary(1 if open_boundary else 0)
+        try:
+            self.h = lib().or_spec_plan_create(C.byref(prm))
+        finally:
+            lib().or_spec_set_open_boundary(0)
         if not self.h:
             raise RuntimeError("or_spec_plan_create failed")
         self.N = prm.N
@@ -200,14 +206,14 @@ class SpecPlan:
         return cls(prm)
 
     @classmethod
-    def explicit(cls, N, A, M, p, mu, L, a, beta, kmax, nthreads=0):
+    def explicit(cls, N, A, M, p, mu, L, a, beta, kmax, nthreads=0, open_boundary=False):
         prm = SpecParams()
         prm.N, prm.p, prm.mu, prm.L, prm.kmax, prm.nthreads = N, p, mu, L, kmax, nthreads
         for d in range(3):
             prm.M[d] = M[d]
             prm.A[d] = A[d]
         prm.a, prm.beta, prm.eps = a, beta, 1e-12
-        return cls(prm)
+        return cls(prm, open_boundary=open_boundary)
 
     def close(self):
         if self.h:

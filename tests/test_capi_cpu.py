@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(msm):
     hdr = open(os.path.join(ROOT, "include", "msm_amd.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     names = set(re.findall(r"\b(msm_amd_\w+|msmperiodic|msmPeriodicRunner|mylog2|choose\w+|minOf3Integers|data_read|"
-                           r"short_range_periodic|print_stats|direct|ewaldClassical\w*|msm4g_linkedlist_\w+)\s*\(", hdr))
+                           r"short_range_periodic|print_stats|direct|msm3d|ewaldClassical\w*|msm4g_linkedlist_\w+)\s*\(", hdr))
     names -= {"msm_amd_plan_desc", "msm_amd_handle", "msm_amd_hostplan"}
     assert len(names) >= 55
     lib = C.CDLL(msm.capi.LIB_PATH)

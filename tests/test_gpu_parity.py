@@ -568,6 +568,108 @@ def test_accuracy_vs_ewald_100k(msm, torch):
     eng.close()
 
 
+def open_system(N, seed, box=(1.0, 1.0, 1.0), shift=(0.0, 0.0, 0.0)):
+    rng = np.random.default_rng(seed)
+    r = rng.random((N, 3)) * np.array(box) + np.array(shift)
+    q = np.where(np.arange(N) % 2 == 0, 1.0, -1.0)
+    return r, q
+
+
+OPEN_CASES = [  # N, box of the particles, shift, p, mu, h, a, L
+    (2000, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), 4, 10, 1 / 12, 4 / 12, 1),
+    (4000, (1.0, 1.0, 1.0), (-3.0, 2.5, 10.0), 4, 10, 1 / 16, 4 / 16, 2),     # away from the origin
+    (6000, (1.0, 0.6, 1.3), (0.2, 0.0, -0.4), 6, 10, 1 / 20, 4 / 20, 2),      # non-cubic cloud, quintic spline
+    (20000, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), 6, 6, 1 / 28, 3.5 / 28, 3),     # tiled spline kernels, three levels
+]
+
+
+@pytest.mark.parametrize("N,box,shift,p,mu,h,a,L", OPEN_CASES)
+def test_open_boundary_parity(msm, torch, N, box, shift, p, mu, h, a, L):
+    """Open-boundary MSM (msm3d of msm/msmLibrary.h:216, defined nowhere in the reference: parity unpinned by reference
+    output) against the CPU oracle's open mode to 1e-12, stage by stage and as one evaluation, and against the
+    direct sum of msm/nonperiodic.c:12-22 within the method's accuracy."""
+    r, q = open_system(N, 40 + N, box, shift)
+    desc = msm.plan_open(N, r.min(axis=0), r.max(axis=0), p, mu, h, a, L)
+    assert desc.open_boundary == 1 and desc.L == L
+    org = np.array(list(desc.origin))
+    sp = O.SpecPlan.explicit(N, list(desc.A), list(desc.M), p, mu, L, a, 1.0, 0, nthreads=8, open_boundary=True)
+    rs = r - org                                   # the oracle works in the cell's own coordinates
+    assert rs.min() > 0 and (rs.max(axis=0) < np.array(list(desc.A))).all()
+    eng = msm.Engine(desc)
+    for l in range(L):
+        K, first = eng.stencil(l)
+        Ko, fo = sp.stencil(l)
+        assert first == fo and K.shape == Ko.shape
+        assert grid_err(K, Ko) < (1e-11 if p == 6 else 1e-12)
+    dev = "cuda:0"
+    rd, qd = torch.as_tensor(r, device=dev), torch.as_tensor(q, device=dev)
+    eng.stage_bin(rd, qd)
+    eng.stage_anterpolate()
+    g0o = sp.anterpolate(rs, q)
+    assert grid_err(eng.grid(msm.capi.GRID_Q, 0), g0o) < TOL
+    ref = sp.eval(rs, q)
+    # coarsest level alone: every node against every node, no wrap-around
+    qL = sp.grid("q", L - 1)
+    e = torch.zeros(qL.shape, dtype=torch.float64, device=dev)
+    eng.op_convolve(L - 1, torch.as_tensor(qL, device=dev), e)
+    assert grid_err(e.cpu().numpy(), sp.convolve(L - 1, qL)) < TOL
+    eng.stage_grid()
+    for l in range(L):
+        assert grid_err(eng.grid(msm.capi.GRID_E, l), sp.grid("e", l)) < TOL
+    en, acc = eng.eval(rd, qd)
+    scale = np.abs(ref["energies"][:6]).max()
+    assert np.abs(en - ref["energies"]).max() < TOL * scale, (en, ref["energies"])
+    assert en[1] == 0.0 and en[2] == 0.0 and en[4] == 0.0      # no self-image, csr or Fourier terms
+    acc = acc.cpu().numpy()
+    assert rel_rms(acc, ref["acc"]) < TOL
+    # physics: the direct sum
+    u, f = msm.direct(r, q)
+    # (at a = 4 h the periodic engine's errors against Ewald are 5e-3 / 7e-4 in the energy and 4e-4 / 1.4e-4 in the
+    # forces for p = 4 / 6; the energy is a small difference of large terms)
+    assert abs(en[6] - u) < (1e-2 if p == 4 else 3e-3) * abs(u)
+    assert rel_rms(acc, f) < (2e-3 if p == 4 else 5e-4)
+    eng.close()
+    sp.close()
+
+
+def test_msm3d_dropin(msm):
+    """msm3d() through the C ABI on host arrays: same numbers as the handle layer on the plan it builds, caller's
+    arrays untouched, direct sum within the method's accuracy; a bad s is refused like a bad p in msmperiodic."""
+    N, p, mu, h, a = 30000, 6, 10, 1 / 32, 4 / 32
+    r, q = open_system(N, 9, (1.0, 1.0, 0.8), (5.0, -1.0, 0.3))
+    r0 = r.copy()
+    u, f, st = msm.msm3d(r, q, p, h, a, mu)
+    assert np.array_equal(r, r0)
+    ud, fd = msm.direct(r, q)
+    assert abs(u - ud) < 3e-3 * abs(ud) and rel_rms(f, fd) < 5e-4
+    assert st.N == N and st.p == p and st.L >= 2 and st.potential_total == u
+    desc = msm.plan_open(N, r.min(axis=0), r.max(axis=0), p, mu, h, a, 0)
+    assert st.L == desc.L and st.Mx == desc.M[0]
+    eng = msm.Engine(desc)
+    en, acc = eng.eval_host(r, q)
+    assert en[6] == u and np.array_equal(acc, f)
+    eng.close()
+    u2, f2, st2 = msm.msm3d(r, q, p, h, a, mu, s=3)
+    assert u2 == 0.0 and st2.potential_total == 0.0
+
+
+def test_open_boundary_large(msm, torch):
+    """Open-boundary MSM at 300k particles (three levels, 32^3 coarsest grid) against the direct sum on the GPU."""
+    N, p, mu = 300000, 6, 10
+    r, q = open_system(N, 11)
+    ht = (1.0 / N) ** (1.0 / 3.0)
+    desc = msm.plan_open(N, r.min(axis=0), r.max(axis=0), p, mu, ht, 4.0 * ht, 0)
+    eng = msm.Engine(desc)
+    rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
+    en, acc = eng.eval(rd, qd)
+    en2, acc2 = eng.eval(rd, qd)
+    assert np.array_equal(en, en2) and torch.equal(acc, acc2)
+    u, f = msm.direct(r, q)
+    assert abs(en[6] - u) < 1e-2 * abs(u)     # the total is what is left of components forty times larger
+    assert rel_rms(acc.cpu().numpy(), f) < 3e-4
+    eng.close()
+
+
 @pytest.mark.parametrize("name", ["changaN8", "changaN64", "changaN512", "NaClN64", "CsClN128"])
 def test_direct_matches_reference_nonperiodic(msm, name):
     """direct() (msm/msmLibrary.h:212) on the GPU == the reference's msm/nonperiodic output (charges forced to 1
