@@ -167,3 +167,39 @@ def test_no_cpu_fallback(msm):
     assert np.isnan(u) and b"no CPU path" in msm.load().msm_amd_last_error()
     u, f = msm.direct(r, q)
     assert u == 0.0 and not f.any() and b"no CPU path" in msm.load().msm_amd_last_error()
+
+
+def test_plan_open(msm):
+    """msm_amd_plan_open: the cell keeps the grid spacing, is a whole number of coarsest cells, holds the particles in
+    its middle with room for the spline supports and the widest compact stencil, and at least three cutoffs."""
+    lo, hi = (-3.0, 2.5, 10.0), (-2.0, 3.1, 11.3)
+    for (N, p, h, a, L) in ((4000, 4, 1 / 16, 0.25, 2), (1000000, 6, 1 / 96, 0.04, 0), (50, 6, 0.5, 2.0, 1), (20000, 6, 1 / 28, 0.125, 3)):
+        d = msm.plan_open(N, lo, hi, p, 10, h, a, L)
+        assert d.open_boundary == 1 and d.kmax == 0 and (L == 0 or d.L == L)
+        hc = h * 2 ** (d.L - 1)
+        for k in range(3):
+            E = hi[k] - lo[k]
+            assert d.M[k] % (2 ** (d.L - 1)) == 0
+            assert abs(d.A[k] - d.M[k] * h) < 1e-12 * d.A[k]
+            room = d.A[k] - E
+            assert room >= (p + 2) * hc - 1e-12 and d.A[k] >= 3 * a
+            if d.L >= 2:
+                assert room >= (p / 2) * hc + 2 ** (d.L - 1) * a
+            assert abs((lo[k] - d.origin[k]) - (d.origin[k] + d.A[k] - hi[k])) < 1e-9
+            assert d.extent[k] == E
+        if L == 0:
+            assert 8 <= max(d.M) >> (d.L - 1) <= 32 or d.L == 1
+    with pytest.raises(msm.MsmAmdError):
+        msm.plan_open(10, lo, hi, 5, 10, 0.1, 0.4, 1)
+    # an open plan builds on the host like a periodic one: no images, no Fourier level
+    d = msm.plan_open(300, (0, 0, 0), (1, 1, 1), 4, 10, 1 / 6, 4 / 6, 2)
+    hp = msm.HostPlan(d)
+    K, first = hp.stencil(d.L - 1)
+    ML = [m >> (d.L - 1) for m in d.M]
+    assert list(K.shape) == [2 * ML[2] - 1, 2 * ML[1] - 1, 2 * ML[0] - 1] and first == [-(ML[0] - 1), -(ML[1] - 1), -(ML[2] - 1)]
+    assert not hp.stencil(d.L)[0].any() and hp.scalars()["csr"] == 0.0 and hp.scalars()["self_image_sum"] == 0.0
+    sp = O.SpecPlan.explicit(300, list(d.A), list(d.M), 4, 10, d.L, d.a, 1.0, 0, nthreads=4, open_boundary=True)
+    for l in range(d.L):
+        Ko, fo = sp.stencil(l)
+        Kh, fh = hp.stencil(l)
+        assert fh == fo and np.abs(Kh - Ko).max() <= 1e-12 * np.abs(Ko).max()

@@ -252,3 +252,29 @@ def test_direct_oracle_matches_reference_nonperiodic(name):
     rm[1, 0] -= eps
     du = (O.direct(rp, np.ones(s["N"]))[0] - O.direct(rm, np.ones(s["N"]))[0]) / (2 * eps)
     assert abs(du - acc[1, 0]) <= 1e-6 * max(abs(du), np.abs(acc).max() * 1e-3)
+
+
+@pytest.mark.parametrize("p,h,abar,L", [(4, 1 / 8, 4.0, 2), (6, 1 / 8, 4.0, 2), (6, 1 / 16, 6.0, 3)])
+def test_spec_open_boundary_vs_direct(p, h, abar, L):
+    """The oracle's open-boundary mode (msm3d of msm/msmLibrary.h:216, defined nowhere in the reference, so no reference
+    output pins it) against the oracle's direct sum, which the real msm/nonperiodic pins: errors at the level of the
+    method and falling with spline order and cutoff; the result does not depend on the number of levels beyond that."""
+    N, mu = 400, 10
+    rng = np.random.default_rng(1)
+    r = rng.random((N, 3))
+    q = np.where(np.arange(N) % 2 == 0, 1.0, -1.0)
+    u, acc = O.direct(r, q)
+    a, hc = abar * h, h * 2 ** (L - 1)
+    need = max((p + 2) * hc, (p / 2) * hc + 2 ** (L - 1) * a + 2 * h)
+    M = int(np.ceil((1 + need) / h))
+    M += (-M) % (2 ** (L - 1))
+    A = M * h
+    sp = O.SpecPlan.explicit(N, [A] * 3, [M] * 3, p, mu, L, a, 1.0, 0, nthreads=8, open_boundary=True)
+    out = sp.eval(r + (A - 1) / 2, q)
+    en = out["energies"]
+    assert en[1] == 0.0 and en[2] == 0.0 and en[4] == 0.0
+    du = abs(en[6] - u) / abs(u)
+    df = np.sqrt(((out["acc"] - acc) ** 2).sum() / (acc ** 2).sum())
+    bar_u, bar_f = {(4, 4.0): (5e-3, 1e-3), (6, 4.0): (2e-4, 5e-4), (6, 6.0): (5e-5, 5e-5)}[(p, abar)]
+    assert du < bar_u and df < bar_f, (du, df)
+    sp.close()
