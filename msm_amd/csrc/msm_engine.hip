@@ -49,6 +49,7 @@ struct msm_amd_handle {
     double *efour = nullptr, *dKL = nullptr, *tmpA = nullptr, *tmpB = nullptr;
     double *dTsum = nullptr, *dTfour = nullptr; // coarsest-level + Fourier stencils as offset tables (both span one period)
     int opt_top_fused = 1;
+    double *open_part = nullptr; // open boundaries: partial sums of the coarsest level's all-pairs convolution
     int opt_sort_two_level = 1; // creation-time choice (MSM_AMD_SORT=0 in the environment selects the sort with global counters)
     // reductions
     double *epart = nullptr;
@@ -388,6 +389,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
                 HIPCHK(hipMemcpy(h->dTfour, tf.data(), nL * sizeof(double), hipMemcpyHostToDevice));
             }
         }
+        if (d.open_boundary) DA(h->open_part, (size_t)conv_open_groups(h->hp.Ml[L - 1]) * nL);
         HIPCHK(hipMemset(h->efour, 0, nL * sizeof(double)));
         HIPCHK(hipMemcpy(h->dKL, h->hp.KL.v.data(), nL * sizeof(double), hipMemcpyHostToDevice));
         DA(h->tmpA, n0 / 2 + 1); DA(h->tmpB, n0 / 4 + 1);
@@ -437,6 +439,7 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     for (auto p : h->dK) hipFree(p);
     for (auto p : h->dKt) hipFree(p);
     for (auto p : h->dKsub) hipFree(p);
+    hipFree(h->open_part);
     hipFree(h->efour); hipFree(h->dKL); hipFree(h->dTsum); hipFree(h->dTfour); hipFree(h->tmpA); hipFree(h->tmpB); hipFree(h->epart); hipFree(h->parts);
     hipFree(h->d_energies);
     if (h->h_energies) hipHostFree(h->h_energies);
@@ -697,7 +700,7 @@ static void top_level(msm_amd_handle *h) {
     const size_t nL = (size_t)ML[0] * ML[1] * ML[2];
     if (h->hp.d.open_boundary) {
         // every node of the coarsest grid against every node, no wrap-around; there is no Fourier level (efour stays 0)
-        launch_conv_open(h->stream, h->gq[L - 1], h->dK[L - 1], ML, h->ge[L - 1]);
+        launch_conv_open(h->stream, h->gq[L - 1], h->dK[L - 1], ML, h->ge[L - 1], h->open_part);
     } else if (top_fused(h)) {
         // the coarsest level's own convolution was left out of the coarse ranges: both in one pass
         launch_conv_small_pair(h->stream, h->gq[L - 1], h->dTsum, h->dTfour, ML, h->ge[L - 1], h->efour);
@@ -1085,7 +1088,7 @@ extern "C" int msm_amd_op_convolve(msm_amd_handle *h, int l, const double *d_q, 
         const int *ML = h->hp.Ml[l - 1];
         conv_untiled(h, d_q, h->dKL, ML, h->hp.KL.size, h->hp.KL.first, d_e, 0, ML[2]);
     } else if (h->hp.d.open_boundary && l == h->hp.d.L - 1) {
-        launch_conv_open(h->stream, d_q, h->dK[l], h->hp.Ml[l], d_e);
+        launch_conv_open(h->stream, d_q, h->dK[l], h->hp.Ml[l], d_e, h->open_part);
     } else {
         convolve_level(h, l, d_q, d_e, 0, h->hp.Ml[l][2]);
     }

@@ -1123,41 +1123,86 @@ __global__ __launch_bounds__(256) void k_conv_direct(const double *__restrict__ 
     e[o] = c.accumulate ? e[o] + s : s;
 }
 
-// Open boundaries, coarsest level: every node against every node, no wrap-around.  A workgroup owns 64 output nodes
-// (one per lane) and its 16 waves share the input rows (nz, ny) between them; the 16 partial sums of a node are added in
-// wave order.  The charge of the inner loop is the same address for the whole wave, the stencil entries of neighbouring
-// lanes are neighbours in memory.
-#define CONV_OPEN_SLICES 16
-__global__ __launch_bounds__(64 * CONV_OPEN_SLICES) void k_conv_open(const double *__restrict__ q, const double *__restrict__ K,
-                                                                     double *__restrict__ e, int Mx, int My, int Mz) {
-    __shared__ double part[CONV_OPEN_SLICES][64];
-    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int n = Mx * My * Mz, idx = min(blockIdx.x * 64 + lane, n - 1); // lanes past the end repeat the last node
-    const int mx = idx % Mx, my = (idx / Mx) % My, mz = idx / (Mx * My);
+// Open boundaries, coarsest level: every node against every node, no wrap-around.
+//
+// A lane owns 8 outputs (mx, my0..my0+7, mz) and meets 8 input rows (ny0..ny0+7, nz) at a time: the 64 products of a
+// step at a given nx need only the 15 stencil rows my - ny = -7..7, so one stencil load (neighbouring lanes = neighbouring
+// mx = neighbouring addresses) feeds four FMAs and the charges are wave-uniform.  The input row groups are shared out
+// over the waves of a workgroup and over gridDim.y workgroups; a workgroup adds its waves' sums in wave order and
+// stores one partial per output, and k_conv_open_sum adds the partials in group order: the order of the additions is
+// fixed by the launch geometry alone.
+#define CONV_OPEN_R 8
+__global__ __launch_bounds__(256) void k_conv_open(const double *__restrict__ q, const double *__restrict__ K,
+                                                   double *__restrict__ part, int Mx, int My, int Mz) {
+    __shared__ double red[3][CONV_OPEN_R][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nyt = (My + CONV_OPEN_R - 1) / CONV_OPEN_R, total = Mx * nyt * Mz;
+    const int flat = min(blockIdx.x * 64 + lane, total - 1); // lanes past the end repeat the last tile
+    const int mx = flat % Mx, yt = (flat / Mx) % nyt, mz = flat / (Mx * nyt), my0 = yt * CONV_OPEN_R;
     const int sx = 2 * Mx - 1, sy = 2 * My - 1;
-    const int rows = My * Mz, per = (rows + CONV_OPEN_SLICES - 1) / CONV_OPEN_SLICES;
-    const int r0 = min(rows, slice * per), r1 = min(rows, r0 + per);
-    double s = 0.0;
-    for (int row = r0; row < r1; row++) {
-        const int nz = row / My, ny = row - nz * My;
-        const double *qrow = q + (size_t)row * Mx;
-        const double *krow = K + ((size_t)(mz - nz + Mz - 1) * sy + (my - ny + My - 1)) * sx + mx + Mx - 1;
-#pragma unroll 8
-        for (int nx = 0; nx < Mx; nx++) s = fma(krow[-nx], qrow[nx], s);
-    }
-    part[slice][lane] = s;
-    __syncthreads();
-    if (slice == 0 && blockIdx.x * 64 + lane < n) {
-        double t = part[0][lane];
+    const int units = Mz * nyt, nsl = gridDim.y * 4, sl = blockIdx.y * 4 + wave;
+    const int per = (units + nsl - 1) / nsl, u0 = min(units, sl * per), u1 = min(units, u0 + per);
+    double acc[CONV_OPEN_R];
 #pragma unroll
-        for (int k = 1; k < CONV_OPEN_SLICES; k++) t += part[k][lane];
-        e[idx] = t;
+    for (int o = 0; o < CONV_OPEN_R; o++) acc[o] = 0.0;
+    for (int u = u0; u < u1; u++) {
+        const int nz = u / nyt, ny0 = (u - nz * nyt) * CONV_OPEN_R;
+        // stencil row my - ny = my0 - ny0 + d, d = -7..7 (rows outside the stencil only meet rows outside the grid)
+        const double *kplane = K + (size_t)(mz - nz + Mz - 1) * sy * sx + mx + Mx - 1;
+        int koff[2 * CONV_OPEN_R - 1];
+#pragma unroll
+        for (int d = 0; d < 2 * CONV_OPEN_R - 1; d++)
+            koff[d] = min(max(my0 - ny0 + d - (CONV_OPEN_R - 1) + My - 1, 0), sy - 1) * sx;
+        const double *qrow = q + ((size_t)nz * My + ny0) * Mx;
+        const int nrows = min(CONV_OPEN_R, My - ny0); // input rows of this group inside the grid (wave-uniform)
+        for (int nx = 0; nx < Mx; nx++) {
+            double w[2 * CONV_OPEN_R - 1], qv[CONV_OPEN_R];
+#pragma unroll
+            for (int d = 0; d < 2 * CONV_OPEN_R - 1; d++) w[d] = kplane[koff[d] - nx];
+#pragma unroll
+            for (int i = 0; i < CONV_OPEN_R; i++) qv[i] = i < nrows ? qrow[(size_t)i * Mx + nx] : 0.0;
+#pragma unroll
+            for (int i = 0; i < CONV_OPEN_R; i++)
+#pragma unroll
+                for (int o = 0; o < CONV_OPEN_R; o++) acc[o] = fma(w[o - i + CONV_OPEN_R - 1], qv[i], acc[o]);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int o = 0; o < CONV_OPEN_R; o++) red[wave - 1][o][lane] = acc[o];
+    }
+    __syncthreads();
+    if (wave == 0 && blockIdx.x * 64 + lane < total) {
+#pragma unroll
+        for (int o = 0; o < CONV_OPEN_R; o++) {
+            const double t = ((acc[o] + red[0][o][lane]) + red[1][o][lane]) + red[2][o][lane];
+            if (my0 + o < My) part[(size_t)blockIdx.y * Mx * My * Mz + ((size_t)mz * My + my0 + o) * Mx + mx] = t;
+        }
     }
 }
 
-void launch_conv_open(hipStream_t st, const double *q, const double *K, const int M[3], double *e) {
-    const long n = (long)M[0] * M[1] * M[2];
-    hipLaunchKernelGGL(k_conv_open, dim3((unsigned)((n + 63) / 64)), dim3(64 * CONV_OPEN_SLICES), 0, st, q, K, e, M[0], M[1], M[2]);
+__global__ __launch_bounds__(256) void k_conv_open_sum(const double *__restrict__ part, double *__restrict__ e, int n, int groups) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double t = part[i];
+    for (int g = 1; g < groups; g++) t += part[(size_t)g * n + i];
+    e[i] = t;
+}
+
+int conv_open_groups(const int M[3]) {
+    const int nyt = (M[1] + CONV_OPEN_R - 1) / CONV_OPEN_R;
+    const long tiles = ((long)M[0] * nyt * M[2] + 63) / 64, units = (long)M[2] * nyt;
+    long g = (1024 + tiles - 1) / tiles;           // about four workgroups per CU
+    g = std::min(g, (units + 3) / 4);              // at least one row group per wave
+    return (int)std::max(1L, std::min(g, 64L));
+}
+
+void launch_conv_open(hipStream_t st, const double *q, const double *K, const int M[3], double *e, double *part) {
+    const int n = M[0] * M[1] * M[2], groups = conv_open_groups(M);
+    const int nyt = (M[1] + CONV_OPEN_R - 1) / CONV_OPEN_R;
+    const unsigned tiles = (unsigned)(((long)M[0] * nyt * M[2] + 63) / 64);
+    hipLaunchKernelGGL(k_conv_open, dim3(tiles, groups), dim3(256), 0, st, q, K, part, M[0], M[1], M[2]);
+    hipLaunchKernelGGL(k_conv_open_sum, dim3((n + 255) / 256), dim3(256), 0, st, part, e, n, groups);
 }
 
 void launch_conv_direct(hipStream_t st, const double *q, const double *K, const int M[3], const int ksize[3],

@@ -174,7 +174,9 @@ void launch_conv_small_pair(hipStream_t st, const double *q, const double *Ta, c
 // ---- grid convolution: e[m] = sum_s K[s] q[(m - (first + s)) mod M] for planes [z0, z0+nz) ----
 // open boundaries: e[m] = sum_n K[m - n] q[n] over the nodes of the grid without wrap-around; K holds every node
 // difference -(M-1)..M-1, x fastest
-void launch_conv_open(hipStream_t st, const double *q, const double *K, const int M[3], double *e);
+// part: conv_open_groups(M) * M[0] * M[1] * M[2] doubles of scratch (partial sums)
+int conv_open_groups(const int M[3]);
+void launch_conv_open(hipStream_t st, const double *q, const double *K, const int M[3], double *e, double *part);
 void launch_conv_direct(hipStream_t st, const double *q, const double *K, const int M[3], const int ksize[3],
                         const int kfirst[3], double *e, int z0, int nz, int accumulate);
 // one wave per output node (small grids with stencils spanning the period)
