@@ -285,7 +285,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
             const double vexp = e * e * e + 6.0 * e * e * a + 3.0 * M_PI * a * a * e + 4.0 / 3.0 * M_PI * a * a * a;
             const double est = 1.5 * vexp * N / (8.0 * vol);
             long half = std::max(192L, ((long)(1.3 * est) + 31) / 32 * 32);
-            const long cap = (1L << 29) / std::max(1, cg.max_clusters) / 2 / 32 * 32; // lists of at most 2 GB
+            const long cap = (1L << 32) / std::max(1, cg.max_clusters) / 2 / 32 * 32; // lists of at most 16 GB
             half = std::max(192L, std::min(half, cap));
             cg.list_stride = (int)(2 * half);
         }

@@ -653,6 +653,33 @@ def test_msm3d_dropin(msm):
     assert u2 == 0.0 and st2.potential_total == 0.0
 
 
+@pytest.mark.parametrize("name", ["changaN8", "changaN64", "changaN512"])
+def test_msm3d_on_reference_systems(msm, name):
+    """msm3d on the systems the real msm/nonperiodic was run on (charges forced to 1 as nonperiodic.c:9-10 does):
+    energy against the reference's printed value and gradient against direct(), within the method's accuracy; edge
+    cases: two particles, one particle, coincident bounding-box faces."""
+    fx = O.golden("nonperiodic_%s.json" % name)
+    s = fx["system"]
+    r = np.array(s["r"]).reshape(-1, 3)
+    q = np.ones(s["N"])
+    ext = (r.max(axis=0) - r.min(axis=0)).max()
+    h = ext / max(2.0, s["N"] ** (1.0 / 3.0))
+    u, f, st = msm.msm3d(r, q, 6, h, 4.0 * h, 10)
+    ud, fd = msm.direct(r, q)
+    assert abs(u - fx["u"]) < 2e-3 * abs(fx["u"]) and abs(ud - fx["u"]) <= 0.6e-8 * abs(fx["u"])
+    assert rel_rms(f, fd) < 2e-3
+    # two particles closer than the cutoff, then further apart than the cutoff; a single particle
+    for d in (0.3, 3.0):
+        r2 = np.array([[0.0, 0.0, 0.0], [d, 0.0, 0.0]])
+        q2 = np.array([1.0, -2.0])
+        u2, f2, _ = msm.msm3d(r2, q2, 6, 0.25, 1.0, 10)
+        assert abs(u2 - (-2.0 / d)) < 2e-3 * (2.0 / d)
+        assert abs(f2[0, 0] - (-2.0 / d ** 2)) < 3e-3 * (2.0 / d ** 2) and abs(f2[1, 0] - (-1.0 / d ** 2)) < 3e-3 / d ** 2
+    u1, f1, _ = msm.msm3d(np.array([[0.4, 0.5, 0.6]]), np.array([3.0]), 4, 0.25, 1.0, 10)
+    # a single particle: what is left is the grid's error on the self term -q^2 gamma(0) / (2 a) = -9.84
+    assert abs(u1) < 3e-3 * 9.84 and np.abs(f1).max() < 1e-2
+
+
 def test_open_boundary_large(msm, torch):
     """Open-boundary MSM at 300k particles (three levels, 32^3 coarsest grid) against the direct sum on the GPU."""
     N, p, mu = 300000, 6, 10
