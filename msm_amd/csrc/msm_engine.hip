@@ -315,7 +315,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         const size_t nslots = (size_t)cg.max_clusters * CL_G;
         // two-level sort: needs the columns (and the fine bins of a column) to fit an LDS histogram
         if (const char *e = getenv("MSM_AMD_SORT")) h->opt_sort_two_level = atoi(e) != 0; // A/B: 0 = one global counter per fine bin
-        cg.sort_blocks = (h->opt_sort_two_level && cg.ncols <= 12288 && cg.nzf <= 4096) ? std::max(1, std::min(512, (N + 2047) / 2048)) : 0;
+        cg.sort_blocks = (h->opt_sort_two_level && cg.ncols <= 16384 && cg.nzf <= 4096) ? std::max(1, std::min(512, (N + 2047) / 2048)) : 0;
         h->clg.sort_blocks = cg.sort_blocks;
         if (cg.sort_blocks) {
             DA(cb.hist, (size_t)cg.sort_blocks * cg.ncols); DA(cb.coltotal, cg.ncols); DA(cb.cpstart, cg.ncols + 1);
