@@ -320,6 +320,15 @@ int msm_amd_hostplan_copy_wprime(msm_amd_hostplan *hp, double *host_out, int *le
 /* scalars: [csr, self_image_sum, gamma(0), chisum, J0, J1, J2, J3] */
 int msm_amd_hostplan_scalars(msm_amd_hostplan *hp, double out[8]);
 
+/* Writes the two stencil cache files of msmSimple into directory dir ("" or NULL: the working directory), in its own
+ * names and format (msm/msmSimple.c:1018-1031: stencil_l00_Mx.._My.._Mz.._nu.._mu...dat; :1196-1209:
+ * stencil_fourier_Mx.._My.._Mz.._nu...dat; one %25.16e value per line, x slowest), for a periodic plan with L = 1 -
+ * msmSimple's two-level method.  An unmodified msmSimple started in that directory with the same grid, nu and mu reads
+ * them instead of spending its run time on the sums.  The first form needs no GPU; the second writes what the
+ * handle's stencils (GPU-built by default) hold. */
+int msm_amd_hostplan_write_msmsimple_cache(msm_amd_hostplan *hp, const char *dir);
+int msm_amd_write_msmsimple_cache(msm_amd_handle *h, const char *dir);
+
 /* device-resident direct sum for particles [i0, i1) against all N (a rank of a multi-GPU run takes a slice of i
  * and the slice energies add up): d_acc[3 (i1 - i0)], d_work[msm_amd_direct_work_doubles(N)], stream = hipStream_t;
  * the slice energy is left in d_work[0] and copied to *u when u != NULL (synchronises).  No counterpart in the

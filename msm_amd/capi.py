@@ -138,6 +138,8 @@ SIGNATURES = {
     "msm_amd_set_profiling": (None, [_vp, C.c_int]),
     "msm_amd_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "msm_amd_hostplan_create": (C.c_int, [C.POINTER(PlanDesc), C.c_int, _vpp]),
+    "msm_amd_hostplan_write_msmsimple_cache": (C.c_int, [_vp, C.c_char_p]),
+    "msm_amd_write_msmsimple_cache": (C.c_int, [_vp, C.c_char_p]),
     "msm_amd_hostplan_destroy": (None, [_vp]),
     "msm_amd_hostplan_stencil_info": (C.c_int, [_vp, C.c_int, _ip, _ip]),
     "msm_amd_hostplan_copy_stencil": (C.c_int, [_vp, C.c_int, _dp]),

@@ -986,6 +986,11 @@ extern "C" int msm_amd_eval_enqueue(msm_amd_handle *h, const double *d_r, const 
     return MSM_AMD_OK;
 }
 
+extern "C" int msm_amd_write_msmsimple_cache(msm_amd_handle *h, const char *dir) {
+    if (!h) return MSM_AMD_EINVAL;
+    return write_msmsimple_cache(h->hp, dir);
+}
+
 extern "C" int msm_amd_last_timings(msm_amd_handle *h, double ms[10]) {
     if (!h || !ms) return MSM_AMD_EINVAL;
     for (int i = 0; i < T_COUNT; i++) ms[i] = h->last_ms[i];

@@ -459,6 +459,43 @@ int build_host_plan(HostPlan &hp, const StencilBackend *be) {
     return MSM_AMD_OK;
 }
 
+// msmSimple's stencil cache files (msm/msmSimple.c:1018-1031 and :1196-1209): one value per line, %25.16e, node
+// offsets mx (slowest), my, mz (fastest) over -(M-1)/2 .. M/2.  Our level-0 stencil covers the same offsets when it
+// spans the period and is zero outside its support otherwise; the Fourier stencil is stored on [0, M)^3.
+int write_msmsimple_cache(const HostPlan &hp, const char *dir) {
+    if (hp.d.L != 1 || hp.literal || hp.d.open_boundary) {
+        set_error("msmSimple's cache files describe a periodic two-level plan (L = 1, not literal)");
+        return MSM_AMD_EINVAL;
+    }
+    const int *M = hp.d.M;
+    int lo[3], hi[3];
+    for (int d = 0; d < 3; d++) { lo[d] = -((M[d] - 1) / 2); hi[d] = M[d] / 2; }
+    const std::string base = (dir && *dir) ? std::string(dir) + "/" : std::string();
+    char name[160];
+    snprintf(name, sizeof(name), "stencil_l%02d_Mx%02d_My%02d_Mz%02d_nu%02d_mu%02d.dat", 0, M[0], M[1], M[2], hp.d.p, hp.d.mu);
+    FILE *fp = fopen((base + name).c_str(), "w");
+    if (!fp) { set_error("cannot write %s", (base + name).c_str()); return MSM_AMD_EINVAL; }
+    const LevelStencil &S = hp.K[0];
+    for (int mx = lo[0]; mx <= hi[0]; mx++)
+        for (int my = lo[1]; my <= hi[1]; my++)
+            for (int mz = lo[2]; mz <= hi[2]; mz++) {
+                const int ix = mx - S.first[0], iy = my - S.first[1], iz = mz - S.first[2];
+                const bool in = ix >= 0 && ix < S.size[0] && iy >= 0 && iy < S.size[1] && iz >= 0 && iz < S.size[2];
+                fprintf(fp, "%25.16e\n", in ? S.v[((size_t)iz * S.size[1] + iy) * S.size[0] + ix] : 0.0);
+            }
+    fclose(fp);
+    snprintf(name, sizeof(name), "stencil_fourier_Mx%02d_My%02d_Mz%02d_nu%02d.dat", M[0], M[1], M[2], hp.d.p);
+    fp = fopen((base + name).c_str(), "w");
+    if (!fp) { set_error("cannot write %s", (base + name).c_str()); return MSM_AMD_EINVAL; }
+    auto wrap = [](int m, int n) { return ((m % n) + n) % n; };
+    for (int mx = lo[0]; mx <= hi[0]; mx++)
+        for (int my = lo[1]; my <= hi[1]; my++)
+            for (int mz = lo[2]; mz <= hi[2]; mz++)
+                fprintf(fp, "%25.16e\n", hp.KL.v[((size_t)wrap(mz, M[2]) * M[1] + wrap(my, M[1])) * M[0] + wrap(mx, M[0])]);
+    fclose(fp);
+    return MSM_AMD_OK;
+}
+
 } // namespace msm
 
 // ---------------------------------------------------------------------------
@@ -511,6 +548,11 @@ int msm_amd_hostplan_scalars(msm_amd_hostplan *h, double out[8]) {
     out[0] = h->hp.csr; out[1] = h->hp.self_image_sum; out[2] = h->hp.gamma0; out[3] = h->hp.chisum;
     for (int k = 0; k < 4; k++) out[4 + k] = h->hp.J[k];
     return MSM_AMD_OK;
+}
+
+int msm_amd_hostplan_write_msmsimple_cache(msm_amd_hostplan *h, const char *dir) {
+    if (!h) return MSM_AMD_EINVAL;
+    return msm::write_msmsimple_cache(h->hp, dir);
 }
 
 double mylog2(double x) { return std::log(x) / std::log(2.0); }

@@ -68,6 +68,9 @@ int build_host_plan(HostPlan &hp, const StencilBackend *be = nullptr);
 // stencil builders on the current HIP device (msm_stencil.hip)
 const StencilBackend *device_stencil_backend();
 
+// the two stencil cache files of msmSimple (msm/msmSimple.c:1018-1031, 1196-1209) for a periodic two-level plan
+int write_msmsimple_cache(const HostPlan &hp, const char *dir);
+
 void set_error(const char *fmt, ...);
 
 } // namespace msm

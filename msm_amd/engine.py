@@ -74,6 +74,10 @@ class HostPlan:
         check(load().msm_amd_hostplan_copy_stencil(self._h, level, out.ctypes.data_as(_dp)), "copy_stencil")
         return out.reshape(size[2], size[1], size[0]), list(first)
 
+    def write_msmsimple_cache(self, directory=""):
+        """msmSimple's two stencil cache files (msm/msmSimple.c:1018-1031, 1196-1209) for this L = 1 plan."""
+        check(load().msm_amd_hostplan_write_msmsimple_cache(self._h, str(directory).encode()), "write_msmsimple_cache")
+
     def wprime(self):
         n = C.c_int(0)
         check(load().msm_amd_hostplan_copy_wprime(self._h, None, C.byref(n)), "copy_wprime")
@@ -233,6 +237,9 @@ class Engine:
         out = np.zeros(size[0] * size[1] * size[2])
         check(load().msm_amd_copy_stencil(self._h, level, out.ctypes.data_as(_dp)), "copy_stencil")
         return out.reshape(size[2], size[1], size[0]), list(first)
+
+    def write_msmsimple_cache(self, directory=""):
+        check(load().msm_amd_write_msmsimple_cache(self._h, str(directory).encode()), "write_msmsimple_cache")
 
     def op_restrict(self, level, fine, coarse):
         check(load().msm_amd_op_restrict(self._h, level, fine.data_ptr(), coarse.data_ptr()), "op_restrict")

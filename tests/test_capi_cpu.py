@@ -203,3 +203,64 @@ def test_plan_open(msm):
         Ko, fo = sp.stencil(l)
         Kh, fh = hp.stencil(l)
         assert fh == fo and np.abs(Kh - Ko).max() <= 1e-12 * np.abs(Ko).max()
+
+
+from test_oracle_golden import SIMPLE, simple_case
+
+
+@pytest.mark.parametrize("fn,sysname,copies", SIMPLE)
+def test_msmsimple_stencil_cache_files(msm, fn, sysname, copies, tmp_path):
+    """The cache files msm_amd writes for msmSimple carry msmSimple's own names, its format, and the values the real
+    msmSimple wrote into its files (fixtures), to the tolerance of msmSimple's image sums (1e-8 relative change,
+    msmSimple.c:16, i.e. 2e-11 of the largest entry on these systems)."""
+    fx, r, q, A = simple_case(fn, sysname, copies)
+    sc, args = fx["scalars"], fx["args"]
+    mu, nu, M = args[2], args[3], args[4:7]
+    d = msm.plan_explicit(len(q), A, M, nu, mu, 1, sc["a"], sc["beta"], int(sc["kmax"]))
+    hp = msm.HostPlan(d)
+    hp.write_msmsimple_cache(tmp_path)
+    f1 = tmp_path / ("stencil_l00_Mx%02d_My%02d_Mz%02d_nu%02d_mu%02d.dat" % (M[0], M[1], M[2], nu, mu))
+    f2 = tmp_path / ("stencil_fourier_Mx%02d_My%02d_Mz%02d_nu%02d.dat" % (M[0], M[1], M[2], nu))
+    for f, key, tol in ((f1, "Kl", 2e-11), (f2, "Kfourier", 1e-12)):
+        lines = f.read_text().splitlines()
+        ref = np.array(fx[key])
+        assert len(lines) == ref.size and all(len(l) == 25 for l in lines)
+        got = np.array([float(l) for l in lines])          # msmSimple reads them back with fscanf("%lf")
+        assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+    with pytest.raises(msm.MsmAmdError):
+        msm.HostPlan(msm.plan_auto(4096, (1.0, 1.0, 1.0), 4, 10, 4.0, 2)).write_msmsimple_cache(tmp_path)
+
+
+def test_real_msmsimple_runs_on_our_cache_files(msm, tmp_path):
+    """The real msmSimple (built from the reference's sources into oracle/_ref when they are present; skipped
+    otherwise), started in a directory that holds the cache files msm_amd wrote, reads them instead of computing its
+    stencils and prints the energies of its own full run (fixture)."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "msmSimple")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/msmSimple not built (no reference sources on this machine)")
+    fn, sysname, copies = SIMPLE[-1]      # changaN64, M = 4: the longest stencil computation among the fixtures
+    fx, r, q, A = simple_case(fn, sysname, copies)
+    sc, args = fx["scalars"], fx["args"]
+    mu, nu, M = args[2], args[3], args[4:7]
+    d = msm.plan_explicit(len(q), A, M, nu, mu, 1, sc["a"], sc["beta"], int(sc["kmax"]))
+    msm.HostPlan(d).write_msmsimple_cache(tmp_path)
+    before = {f.name: f.read_bytes() for f in tmp_path.iterdir()}
+    assert len(before) == 2
+    res = subprocess.run([exe, str(args[0]), repr(float(args[1])), str(mu), str(nu), str(M[0]), str(M[1]), str(M[2]), "1"],
+                         cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-500:]
+    for name, data in before.items():
+        assert (tmp_path / name).read_bytes() == data          # read, not rewritten
+    got = {}
+    for ln in res.stdout.splitlines():
+        m = re.match(r"^(\S[^:]*?)\s*:\s*([-+0-9.eEnaif]+)\s*$", ln)
+        if m and m.group(1).strip() not in got:
+            try:
+                got[m.group(1).strip()] = float(m.group(2))
+            except ValueError:
+                pass
+    scale = abs(sc["ushort_real"]) + abs(sc["ulong_self"])
+    for k in ("ulong_real", "ulong_four", "utotal"):
+        assert abs(got[k] - sc[k]) <= 2e-10 * max(abs(sc[k]), 1e-3 * scale), (k, got[k], sc[k])
+    assert got["time_stencilKl"] < 0.05 * max(sc["time_stencilKl"], 1e-3) or got["time_stencilKl"] < 0.01
