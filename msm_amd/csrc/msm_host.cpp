@@ -406,6 +406,12 @@ int build_host_plan(HostPlan &hp, const StencilBackend *be) {
         set_error("open-boundary plans have no literal mode and no slab decomposition");
         return MSM_AMD_EINVAL;
     }
+    if (d.open_boundary && (long)(d.M[0] >> (d.L - 1)) * (d.M[1] >> (d.L - 1)) * (d.M[2] >> (d.L - 1)) > 48L * 48 * 48) {
+        // the coarsest level of an open plan couples every pair of its nodes
+        set_error("open-boundary plan: coarsest grid %d x %d x %d is too large for the all-pairs top level, use more levels",
+                  d.M[0] >> (d.L - 1), d.M[1] >> (d.L - 1), d.M[2] >> (d.L - 1));
+        return MSM_AMD_ERANGE;
+    }
     if (hp.literal && (d.L != 1 || d.p != 4 || d.mu + d.p / 2 > 13)) {
         set_error("literal mode needs L=1, p=4, mu<=11 (msmPeriodic.c:100-104, msmLibrary.c:64-66, msmLibrary.h:14)");
         return MSM_AMD_EINVAL;
@@ -677,7 +683,7 @@ int msm_amd_plan_open(int N, const double lo[3], const double hi[3], int p, int 
     //   the pair sum wants at least three cutoffs per axis.
     auto room = [&](int levels, double Ek) {
         const double hc = std::ldexp(h, levels - 1);
-        double need = (p + 2) * hc;
+        double need = std::max((p + 2) * hc, a + 2 * h); // (no pair may come within the cutoff through the wrap either)
         if (levels >= 2) need = std::max(need, (p / 2) * hc + std::ldexp(a, levels - 1) + 2 * h);
         return std::max(need, 3.05 * a - Ek);
     };

@@ -191,6 +191,12 @@ def test_plan_open(msm):
             assert 8 <= max(d.M) >> (d.L - 1) <= 32 or d.L == 1
     with pytest.raises(msm.MsmAmdError):
         msm.plan_open(10, lo, hi, 5, 10, 0.1, 0.4, 1)
+    # one level and a long cutoff: still no pair within the cutoff through the wrap
+    d = msm.plan_open(1000, (0, 0, 0), (4, 4, 4), 4, 10, 0.1, 1.0, 1)
+    assert min(d.A) - 4.0 >= 1.0
+    # a coarsest grid too large for the all-pairs top level is refused when the plan is built
+    with pytest.raises(msm.MsmAmdError):
+        msm.HostPlan(msm.plan_open(100000, (0, 0, 0), (1, 1, 1), 4, 10, 1 / 64, 4 / 64, 1))
     # an open plan builds on the host like a periodic one: no images, no Fourier level
     d = msm.plan_open(300, (0, 0, 0), (1, 1, 1), 4, 10, 1 / 6, 4 / 6, 2)
     hp = msm.HostPlan(d)
