@@ -10,6 +10,10 @@ collectives (RCCL over xGMI when the backend is "nccl"):
      asynchronously so that it overlaps the pair kernel, which does not depend on it;
   2. all-reduce of five scalars (pair energy, q.e over owned planes, Fourier term, sum q, sum q^2).
 
+When the particles have moved (a time-stepping loop writes new positions of the owned particles into SlabRank.r),
+SlabRank.exchange() migrates particles to their new owners and rebuilds every rank's halo with two all-to-all
+collectives (counts, then records of x, y, z, q and the global index) - the particle halo exchange.
+
 The level-0 convolution — the only grid stage with real work — is evaluated by each rank on its own planes
 plus p/2 planes either side (the interpolation support), so potentials need no halo exchange either.
 """
@@ -55,14 +59,14 @@ class SlabRank:
     interface (tests inject a CPU stand-in to exercise the partition and collective logic without a GPU)."""
 
     def __init__(self, torch, dist, msm_amd, desc, r_all, q_all, rank, world, local_rank=0, margin=2e-4,
-                 engine_factory=None, perturb=True):
+                 engine_factory=None, perturb=True, headroom=1.02):
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
         self.z0, self.nz = slab_planes(desc.M[2], world, rank)
         own, hal = select_slab(r_all, desc.A[2], desc.M[2], world, rank, halo_width(desc, margin if perturb else 0.0))
         self.own_idx, self.halo_idx = own, hal
         n_own, n_tot = len(own), len(own) + len(hal)
         d = copy.copy(desc)
-        d.N = int(n_tot * 1.02) + 64       # capacity; the counts of a step are set with set_counts
+        d.N = int(n_tot * headroom) + 64   # capacity; the counts of a step are set with set_counts
         d.zplane0, d.nzplanes, d.n_owned = self.z0, self.nz, 0
         self.eng = engine_factory(d) if engine_factory else msm_amd.Engine(d, device=local_rank)
         self.eng.set_counts(n_tot, n_own)
@@ -71,7 +75,9 @@ class SlabRank:
         self.r = torch.as_tensor(np.ascontiguousarray(np.asarray(r_all)[idx]), device=dev)
         self.q = torch.as_tensor(np.ascontiguousarray(np.asarray(q_all)[idx]), device=dev)
         self.acc = torch.zeros((n_tot, 3), dtype=torch.float64, device=dev)
-        self.n_own, self.n_tot = n_own, n_tot
+        self.n_own, self.n_tot, self.capacity = n_own, n_tot, d.N
+        self.gid = torch.as_tensor(idx.astype(np.int64), device=dev)   # global index of every held particle
+        self.Az, self.halo, self.margin = desc.A[2], halo_width(desc, margin if perturb else 0.0), margin
         self.q0 = self.eng.grid_tensor(capi.GRID_Q, 0)          # (Mz, My, Mx) view of the engine's level-0 charges
         self.send = torch.empty_like(self.q0[self.z0:self.z0 + self.nz])
         self.sums = self.eng.raw_sums_tensor()
@@ -82,6 +88,68 @@ class SlabRank:
             self.delta = (torch.rand(self.r.shape, generator=g, dtype=torch.float64, device=dev) - 0.5) * margin
             self.sign = 1.0
         self._pending = self._energies = None
+
+    def exchange(self):
+        """Particle migration and halo refresh after the owned particles have moved (self.r[:n_own] rewritten by the
+        caller; halo rows are ignored).  Ownership and halo membership follow select_slab's expressions on the new
+        positions; every rank sends each of its owned particles to the new owner and to every rank whose halo it
+        falls in, owned records before halo records, so a receiver holds [owned from rank 0, 1, ... | halo from rank
+        0, 1, ...].  Two collectives: all-to-all of the counts, all-to-all of the records."""
+        t, W = self.torch, self.world
+        n = self.n_own
+        r, q, gid = self.r[:n], self.q[:n], self.gid[:n]
+        zf = r[:, 2] / self.Az
+        zf = zf - t.floor(zf)
+        edges = t.arange(W + 1, dtype=t.float64, device=r.device) / W   # k / W: the bounds select_slab compares with
+        owner = t.clamp(t.bucketize(zf, edges, right=True) - 1, 0, W - 1)
+        hf = self.halo / self.Az
+        rec = t.cat([r, q[:, None], gid.to(t.float64)[:, None]], dim=1)   # global indices below 2^53 are exact
+        own_parts, halo_parts, counts = [], [], t.zeros((W, 2), dtype=t.int64)
+        for k in range(W):
+            lo, hi = edges[k], edges[k + 1]
+            mine = owner == k
+            below = t.remainder(lo - zf, 1.0)
+            above = t.remainder(zf - hi, 1.0)
+            halo = (~mine) & ((below <= hf) | (above < hf))
+            own_parts.append(rec[mine])
+            halo_parts.append(rec[halo])
+            counts[k, 0], counts[k, 1] = int(mine.sum()), int(halo.sum())
+        send = t.cat([x for k in range(W) for x in (own_parts[k], halo_parts[k])], dim=0)
+        staged = self._host_staged()
+        cdev = "cpu" if staged or self.dist.get_backend() == "gloo" else r.device
+        cs, cr = counts.to(cdev), t.zeros((W, 2), dtype=t.int64, device=cdev)
+        self.dist.all_to_all_single(cr, cs)
+        cr = cr.cpu()
+        in_rows = [int(cr[k, 0] + cr[k, 1]) for k in range(W)]
+        out_rows = [int(counts[k, 0] + counts[k, 1]) for k in range(W)]
+        send_b = send.cpu() if staged else send
+        recv = t.empty((sum(in_rows), 5), dtype=t.float64, device=send_b.device)
+        self.dist.all_to_all_single(recv, send_b, output_split_sizes=in_rows, input_split_sizes=out_rows)
+        recv = recv.to(r.device)
+        owned, halo, at = [], [], 0
+        for k in range(W):
+            no, nh = int(cr[k, 0]), int(cr[k, 1])
+            owned.append(recv[at:at + no])
+            halo.append(recv[at + no:at + no + nh])
+            at += no + nh
+        new = t.cat(owned + halo, dim=0)
+        n_own, n_tot = sum(int(cr[k, 0]) for k in range(W)), new.shape[0]
+        if n_tot > self.capacity:
+            raise RuntimeError("slab rank %d: %d particles (owned + halo) exceed the engine's capacity %d; create the "
+                               "SlabRank with a larger headroom" % (self.rank, n_tot, self.capacity))
+        self.r = new[:, 0:3].contiguous()
+        self.q = new[:, 3].contiguous()
+        self.gid = new[:, 4].to(t.int64)
+        self.acc = t.zeros((n_tot, 3), dtype=t.float64, device=r.device)
+        self.n_own, self.n_tot = n_own, n_tot
+        ids = self.gid.cpu().numpy()
+        self.own_idx, self.halo_idx = ids[:n_own], ids[n_own:]
+        self.eng.set_counts(n_tot, n_own)
+        if self.perturb:
+            g = t.Generator(device=r.device)
+            g.manual_seed(7 + self.rank)
+            self.delta = (t.rand(self.r.shape, generator=g, dtype=t.float64, device=r.device) - 0.5) * self.margin
+            self.sign = 1.0
 
     def _host_staged(self):
         # a gloo group cannot move device memory: stage through the host (functional testing on one GPU)

@@ -63,6 +63,59 @@ def test_slab_ranks_match_single_gpu(tmp_path, world, N, p, L):
     assert err < 1e-12, err
 
 
+def moved(r):
+    i = np.arange(len(r))
+    return r + np.stack([0.03 * np.cos(0.7 * i), 0.05 * np.sin(1.3 * i), 0.11 * np.sin(0.37 * i)], axis=1)
+
+
+def _exchange_worker(rank, world, port, N, p, L, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)
+    import torch
+    import torch.distributed as dist
+    import msm_amd
+    from msm_amd.slab import SlabRank
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=43)
+    desc = msm_amd.plan_auto(N, (1.0, 1.0, 1.0), p, 10, 4.0, L)
+    sr = SlabRank(torch, dist, msm_amd, desc, r, q, rank, world, local_rank=0, perturb=False, headroom=1.3)
+    sr.step()
+    rn = moved(r)
+    sr.r[:sr.n_own] = torch.as_tensor(rn[sr.own_idx], device=sr.r.device)
+    sr.exchange()
+    en = sr.step()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), en=en, idx=sr.own_idx, acc=sr.owned_acc().cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slab_exchange_on_gpu(tmp_path):
+    """Particles move across slab boundaries; after SlabRank.exchange() four ranks (sharing cuda:0) reproduce the
+    single-GPU evaluation of the new positions."""
+    import torch.multiprocessing as mp
+    import msm_amd
+    world, N, p, L = 4, 40000, 6, 3
+    mp.spawn(_exchange_worker, args=(world, _free_port(), N, p, L, str(tmp_path)), nprocs=world, join=True)
+    r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=43)
+    rn = moved(r)
+    desc = msm_amd.plan_auto(N, (1.0, 1.0, 1.0), p, 10, 4.0, L)
+    eng = msm_amd.Engine(desc)
+    en1, acc1 = eng.eval(rn, q)
+    acc1 = acc1.cpu().numpy()
+    acc = np.zeros((N, 3))
+    seen = np.zeros(N, dtype=int)
+    scale = np.abs(en1[:6]).max()
+    for k in range(world):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % k))
+        acc[z["idx"]] = z["acc"]
+        seen[z["idx"]] += 1
+        assert np.abs(z["en"] - en1).max() < 1e-12 * scale, (k, z["en"], en1)
+    assert (seen == 1).all()
+    assert np.sqrt(((acc - acc1) ** 2).sum() / (acc1 ** 2).sum()) < 1e-12
+
+
 def _direct_worker(rank, world, port, N, out_dir):
     import faulthandler
     faulthandler.dump_traceback_later(100, exit=True)

@@ -127,6 +127,64 @@ def _worker(rank, world, port, N, M, L, p, out_dir):
     dist.destroy_process_group()
 
 
+def moved(r):
+    """Displacements large enough to carry many particles across slab boundaries (and some out of the cell)."""
+    i = np.arange(len(r))
+    return r + np.stack([0.03 * np.cos(0.7 * i), 0.05 * np.sin(1.3 * i), 0.11 * np.sin(0.37 * i)], axis=1)
+
+
+def _exchange_worker(rank, world, port, N, M, L, p, out_dir):
+    import torch
+    import torch.distributed as dist
+    import msm_amd
+    from msm_amd.slab import SlabRank, select_slab, halo_width
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=42)
+    q = q * (1.0 + 0.1 * np.sin(np.arange(N)))
+    desc = msm_amd.plan_explicit(N, (1.0, 1.0, 1.0), (M, M, M), p, 6, L, 0.16, 9.0, 8)
+    sr = SlabRank(torch, dist, msm_amd, desc, r, q, rank, world, engine_factory=OracleEngine, perturb=False, headroom=1.5)
+    sr.step()
+    rn = moved(r)
+    sr.r[:sr.n_own] = torch.as_tensor(rn[sr.own_idx])     # what an integrator does: new positions of the owned particles
+    sr.exchange()
+    own, hal = select_slab(rn, 1.0, M, world, rank, halo_width(desc))
+    assert set(sr.own_idx) == set(own) and set(sr.halo_idx) == set(hal)
+    assert np.array_equal(sr.r.numpy(), rn[np.concatenate([sr.own_idx, sr.halo_idx])])
+    assert np.array_equal(sr.q.numpy(), q[np.concatenate([sr.own_idx, sr.halo_idx])])
+    en = sr.step()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), en=en, idx=sr.own_idx, acc=sr.owned_acc().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,p,L", [(2, 4, 2), (3, 6, 1)])
+def test_exchange_migrates_particles_and_rebuilds_halos(tmp_path, world, p, L):
+    """After the particles have moved, SlabRank.exchange() (two all-to-all collectives) leaves every rank with
+    exactly the owned and halo particles select_slab gives for the new positions, and the evaluation equals the
+    single-rank result on the new positions."""
+    import torch.multiprocessing as mp
+    N, M = 1500, 12
+    mp.spawn(_exchange_worker, args=(world, _free_port(), N, M, L, p, str(tmp_path)), nprocs=world, join=True)
+    r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=42)
+    q = q * (1.0 + 0.1 * np.sin(np.arange(N)))
+    rn = moved(r)
+    sp = O.SpecPlan.explicit(N, (1.0, 1.0, 1.0), (M, M, M), p, 6, L, 0.16, 9.0, 8, nthreads=4)
+    ref = sp.eval(rn, q)
+    acc = np.zeros((N, 3))
+    seen = np.zeros(N, dtype=int)
+    for k in range(world):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % k))
+        acc[z["idx"]] = z["acc"]
+        seen[z["idx"]] += 1
+        scale = np.abs(ref["energies"][:6]).max()
+        assert np.abs(z["en"] - ref["energies"]).max() < 1e-12 * scale, (k, z["en"], ref["energies"])
+    assert (seen == 1).all()
+    err = np.sqrt(((acc - ref["acc"]) ** 2).sum() / (ref["acc"] ** 2).sum())
+    assert err < 1e-12, err
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
