@@ -242,7 +242,7 @@ __global__ __launch_bounds__(1024) void k_cs_colscan(const int *__restrict__ col
 __global__ __launch_bounds__(256) void k_cs_scatter(const double *__restrict__ r, const double *__restrict__ q, int N, ClusterGeom g,
                                                     int per_block, const int *__restrict__ bin_of, const int *__restrict__ hist,
                                                     const int *__restrict__ cpstart, double4 *__restrict__ bps,
-                                                    int *__restrict__ bidx, int *__restrict__ bzf) {
+                                                    int2 *__restrict__ bkey) {
     extern __shared__ int cursor[];
     for (int c = threadIdx.x; c < g.ncols; c += 256) cursor[c] = cpstart[c] + hist[(size_t)blockIdx.x * g.ncols + c];
     __syncthreads();
@@ -257,8 +257,7 @@ __global__ __launch_bounds__(256) void k_cs_scatter(const double *__restrict__ r
             f[d] = (t - floor(t)) * g.A[d];
         }
         bps[pos] = make_double4(f[0], f[1], f[2], q[i]);
-        bidx[pos] = i;
-        bzf[pos] = b - col * g.nzf;
+        bkey[pos] = make_int2(i, b - col * g.nzf); // (original index, fine bin inside the column)
     }
 }
 
@@ -279,7 +278,7 @@ __global__ __launch_bounds__(256) void k_cs_colsort(ClusterGeom g, ClusterBuffer
     for (int z = threadIdx.x; z < g.nzf; z += 256) zh[z] = 0;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int e = threadIdx.x; e < n; e += 256) atomicAdd(&zh[b.bzf[p0 + e]], 1);
+    for (int e = threadIdx.x; e < n; e += 256) atomicAdd(&zh[b.bkey[p0 + e].y], 1);
     __syncthreads();
     // zs[z] = particles of the column in fine bins below z; start[col * nzf + z] = p0 + zs[z]
     for (int base = 0; base < g.nzf; base += 256) {
@@ -309,12 +308,13 @@ __global__ __launch_bounds__(256) void k_cs_colsort(ClusterGeom g, ClusterBuffer
         for (int z = threadIdx.x; z < g.nzf; z += 256) zh[z] = 0;
         __syncthreads();
         for (int e = threadIdx.x; e < n; e += 256) {
-            const int z = b.bzf[p0 + e];
-            u.member[zs[z] + atomicAdd(&zh[z], 1)] = b.bidx[p0 + e];
+            const int2 k = b.bkey[p0 + e];
+            u.member[zs[k.y] + atomicAdd(&zh[k.y], 1)] = k.x;
         }
         __syncthreads();
         for (int e = threadIdx.x; e < n; e += 256) {
-            const int z = b.bzf[p0 + e], idx = b.bidx[p0 + e];
+            const int2 k = b.bkey[p0 + e];
+            const int z = k.y, idx = k.x;
             const int m0 = zs[z], m1 = m0 + zh[z];
             int rank = m0;
             for (int m = m0; m < m1; m++) rank += u.member[m] < idx;
@@ -327,13 +327,13 @@ __global__ __launch_bounds__(256) void k_cs_colsort(ClusterGeom g, ClusterBuffer
         for (int e0 = 0; e0 < n; e0 += 256) {
             const int e = e0 + threadIdx.x;
             unsigned long long key = 0;
-            if (e < n) key = ((unsigned long long)(unsigned)b.bzf[p0 + e] << 32) | (unsigned)b.bidx[p0 + e];
+            if (e < n) { const int2 k = b.bkey[p0 + e]; key = ((unsigned long long)(unsigned)k.y << 32) | (unsigned)k.x; }
             int rank = 0;
             for (int j0 = 0; j0 < n; j0 += CS_CHUNK) {
                 const int m = min(CS_CHUNK, n - j0);
                 __syncthreads();
                 for (int j = threadIdx.x; j < m; j += 256)
-                    u.keys[j] = ((unsigned long long)(unsigned)b.bzf[p0 + j0 + j] << 32) | (unsigned)b.bidx[p0 + j0 + j];
+                    { const int2 k = b.bkey[p0 + j0 + j]; u.keys[j] = ((unsigned long long)(unsigned)k.y << 32) | (unsigned)k.x; }
                 __syncthreads();
                 if (e < n)
                     for (int j = 0; j < m; j++) rank += u.keys[j] < key;
@@ -380,7 +380,7 @@ static void launch_cluster_sort2(hipStream_t st, const double *d_r, const double
     hipLaunchKernelGGL(k_cs_blockscan, dim3((g.ncols + 63) / 64), dim3(1024), 0, st, b.hist, nblk, g.ncols, b.coltotal);
     hipLaunchKernelGGL(k_cs_colscan, dim3(1), dim3(1024), 0, st, b.coltotal, g, b.colncl, b.clstart, b.cpstart);
     hipLaunchKernelGGL(k_cs_scatter, dim3(nblk), dim3(256), lds_cols, st, d_r, d_q, N, g, per_block, bin_of, b.hist, b.cpstart,
-                       b.bps, b.bidx, b.bzf);
+                       b.bps, b.bkey);
     hipLaunchKernelGGL(k_cs_colsort, dim3(g.ncols), dim3(256), 2 * sizeof(int) * (size_t)g.nzf, st, g, b);
 }
 

@@ -319,7 +319,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         h->clg.sort_blocks = cg.sort_blocks;
         if (cg.sort_blocks) {
             DA(cb.hist, (size_t)cg.sort_blocks * cg.ncols); DA(cb.coltotal, cg.ncols); DA(cb.cpstart, cg.ncols + 1);
-            DA(cb.bps, N); DA(cb.bidx, N); DA(cb.bzf, N);
+            DA(cb.bps, N); DA(cb.bkey, N);
         }
         DA(cb.count, cg.nbins); DA(cb.start, cg.nbins + 1);
         DA(cb.colncl, cg.ncols + 1); DA(cb.clstart, cg.ncols + 1);
@@ -430,7 +430,7 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     hipFree(h->scan_tmp); hipFree(h->tile_scratch); hipFree(h->tile_used);
     {
         ClusterBuffers &cb = h->clb;
-        hipFree(cb.hist); hipFree(cb.coltotal); hipFree(cb.cpstart); hipFree(cb.bps); hipFree(cb.bidx); hipFree(cb.bzf);
+        hipFree(cb.hist); hipFree(cb.coltotal); hipFree(cb.cpstart); hipFree(cb.bps); hipFree(cb.bkey);
         hipFree(cb.count); hipFree(cb.start); hipFree(cb.colncl); hipFree(cb.clstart); hipFree(cb.order);
         hipFree(cb.ps); hipFree(cb.blo); hipFree(cb.bhi); hipFree(cb.fbox); hipFree(cb.list); hipFree(cb.n0); hipFree(cb.n1); hipFree(cb.n2);
     }

@@ -100,7 +100,7 @@ struct ClusterBuffers {
     // particles as they land in their column's bucket (any order inside a bucket)
     int *hist, *coltotal, *cpstart;
     double4 *bps;
-    int *bidx, *bzf;
+    int2 *bkey;                 // (original index, fine bin inside the column) of a bucket entry
 };
 void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, int N, const ClusterGeom &g,
                          const ClusterBuffers &b, int *bin_of, int *arrival, int *slot_idx, int *scan_tmp);
