@@ -480,17 +480,23 @@ __device__ __forceinline__ void cl_enumerate(const ClusterGeom &g, const Cluster
     const int ex0 = (int)floor((ib.lox - a) * g.inv_pitch[0] - eps), ex1 = (int)floor((ib.hix + a) * g.inv_pitch[0] + eps);
     const int ey0 = (int)floor((ib.loy - a) * g.inv_pitch[1] - eps), ey1 = (int)floor((ib.hiy + a) * g.inv_pitch[1] + eps);
     const float ilz = __double2float_rd(ib.loz), ihz = __double2float_ru(ib.hiz);
-    // lanes cover 8 x 8 columns of the extended column grid at a time
-    for (int by = ey0; by <= ey1; by += 8)
-    for (int bx = ex0; bx <= ex1; bx += 8) {
+    // Lanes cover the columns of the extended column grid, row by row, `per` columns at a time with 64 / per lanes to a
+    // column, which take its candidates in turn: a footprint of 36 columns is walked as 32 columns with two lanes each
+    // and 4 columns with sixteen lanes each, in little more than half the steps of one lane per column.
+    const int nx = ex1 - ex0 + 1, ncol = nx * (ey1 - ey0 + 1);
+    for (int c0 = 0, per = 64; c0 < ncol; c0 += per) {
+        const int rem = ncol - c0;
+        per = rem > 48 ? 64 : (rem > 16 ? 32 : (rem > 8 ? 16 : (rem > 4 ? 8 : 4)));
+        const int nsub = 64 / per, sub = lane / per, lcol = lane - sub * per;
         ColCursor c;
-        const int exi = bx + (lane & 7), eyi = by + (lane >> 3);
+        const int ci = c0 + lcol, row = ci / nx;
+        const int exi = ex0 + (ci - row * nx), eyi = ey0 + row;
         int total = 0;
-        if (exi <= ex1 && eyi <= ey1 && cl_column(g, a2, ib, exi, eyi, c)) {
+        if (ci < ncol && cl_column(g, a2, ib, exi, eyi, c)) {
             cl_ranges(g, b.start, b.clstart, c);
             total = c.n0 + c.n1 + c.n2;
         }
-        for (int t = 0; __ballot(t < total); t++) {
+        for (int t = sub; __ballot(t < total); t += nsub) {
             const bool live = t < total;
             int jcl = 0, code = CL_NOSHIFT;
             bool keep = false;
