@@ -490,6 +490,7 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "conv_tiled")) { h->opt_conv_tiled = value; return MSM_AMD_OK; }
     if (!strcmp(key, "conv_small")) { h->opt_conv_small = value; return MSM_AMD_OK; }
     if (!strcmp(key, "anterp_tiled")) { h->opt_anterp_tiled = value; return MSM_AMD_OK; }
+    if (!strcmp(key, "interp_threads")) { if (value >= 64 && value <= 512 && value % 64 == 0) { interp_threads = value; return MSM_AMD_OK; } }
     if (!strcmp(key, "anterp_cols_waves")) { if (value == 0 || value == 4 || value == 8 || value == 16) { anterp_cols_waves = value; return MSM_AMD_OK; } }
     if (!strcmp(key, "anterp_cols_order4")) { anterp_cols_order4 = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "anterp_cols")) { anterp_cols_enabled = value != 0; return MSM_AMD_OK; } // process-wide A/B switch

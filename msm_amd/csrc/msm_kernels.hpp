@@ -132,6 +132,7 @@ struct TileSrc {
 };
 extern bool anterp_cols_enabled;
 extern int anterp_cols_waves;
+extern int interp_threads;
 extern bool anterp_cols_order4;
 bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, double *scratch,
                          int *tile_used, double *grid);

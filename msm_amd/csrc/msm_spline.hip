@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_anterp_combine(const double *__restrict
 // (periodic wrap applied while staging), then every thread takes one particle of the tile and sums its p^3
 // nodes out of LDS.  acc_i += f sum_m e_m grad Phi_m(r_i), f by the acceleration convention.
 template <int P>
-__global__ __launch_bounds__(256) void k_interp_tiles(TileSrc S, SplineParams sp, TileGeom tl, const double *__restrict__ e,
+__global__ __launch_bounds__(512) void k_interp_tiles(TileSrc S, SplineParams sp, TileGeom tl, const double *__restrict__ e,
                                                       double *__restrict__ acc) {
     constexpr int R = AT + P - 1, R3 = R * R * R;
     __shared__ double blk[R3];
@@ -354,13 +354,13 @@ __global__ __launch_bounds__(256) void k_interp_tiles(TileSrc S, SplineParams sp
     // the tile's particles may be shared between gridDim.y workgroups (a rank that owns a thin slab has few tiles)
     const int share = (total + gridDim.y - 1) / gridDim.y, idx_end = min(total, ((int)blockIdx.y + 1) * share);
     if ((int)blockIdx.y * share >= total) return;
-    for (int t = threadIdx.x; t < R3; t += 256) {
+    for (int t = threadIdx.x; t < R3; t += blockDim.x) {
         const int lx = t % R, ly = (t / R) % R, lz = t / (R * R);
         const int gx = modp(x0 - (P / 2 - 1) + lx, Mx), gy = modp(y0 - (P / 2 - 1) + ly, My), gz = modp(z0 - (P / 2 - 1) + lz, Mz);
         blk[t] = e[((size_t)gz * My + gy) * Mx + gx];
     }
     __syncthreads();
-    for (int idx = blockIdx.y * share + threadIdx.x; idx < idx_end; idx += 256) {
+    for (int idx = blockIdx.y * share + threadIdx.x; idx < idx_end; idx += blockDim.x) {
         int lo = 0, hi = nrows; // row with rowstart[row] <= idx < rowstart[row+1]
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -416,13 +416,16 @@ __global__ __launch_bounds__(256) void k_interp_tiles(TileSrc S, SplineParams sp
     }
 }
 
+int interp_threads = 256;        // threads of a tile workgroup of the interpolation kernel (multiple of 64, at most 512)
+
 void launch_interp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, const double *egrid,
                          double *acc) {
     // gridDim.y > 1 shares a tile's particles between workgroups; measured slower even for a rank that owns a thin
     // slab (every workgroup stages the tile's block of potentials again), so one workgroup per tile it is
     const int ns = 1;
-    if (sp.p == 4) hipLaunchKernelGGL((k_interp_tiles<4>), dim3(tl.ntiles, ns), dim3(256), 0, st, S, sp, tl, egrid, acc);
-    else hipLaunchKernelGGL((k_interp_tiles<6>), dim3(tl.ntiles, ns), dim3(256), 0, st, S, sp, tl, egrid, acc);
+    const int nthreads = interp_threads;
+    if (sp.p == 4) hipLaunchKernelGGL((k_interp_tiles<4>), dim3(tl.ntiles, ns), dim3(nthreads), 0, st, S, sp, tl, egrid, acc);
+    else hipLaunchKernelGGL((k_interp_tiles<6>), dim3(tl.ntiles, ns), dim3(nthreads), 0, st, S, sp, tl, egrid, acc);
 }
 
 int anterp_cols_waves = 0;        // waves per tile workgroup of the column kernel: 4, 8, 16, or 0 = by the share of owned planes
