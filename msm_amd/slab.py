@@ -198,7 +198,6 @@ class SlabRank:
         eng.stage_raw_sums()
         mark("end")
         s = self.sums.clone()
-        s[2] = s[2] / self.world           # the Fourier term is replicated on every rank
         if self._host_staged():
             s = s.cpu()
         self.dist.all_reduce(s)
@@ -208,7 +207,9 @@ class SlabRank:
     @property
     def last_energies(self):
         if self._energies is None and self._pending is not None:
-            self._energies = self.eng.combine_energies(self._pending.cpu().numpy())
+            sums = self._pending.cpu().numpy().copy()
+            sums[2] /= self.world          # the Fourier term is replicated on every rank: the all-reduce added it W times
+            self._energies = self.eng.combine_energies(sums)
         return self._energies
 
     def owned_acc(self):
