@@ -373,14 +373,21 @@ __global__ __launch_bounds__(512) void k_interp_tiles(TileSrc S, SplineParams sp
         const double ux = pt.x * S.scale[0], uy = pt.y * S.scale[1], uz = pt.z * S.scale[2];
         const int cellx = tile_cell(ux, x0, nxc), ry = tile_cell(uy, y0, nyc) - y0, rz = tile_cell(uz, z0, nzc) - z0;
         const double f[3] = {ux - (double)cellx, uy - (double)(y0 + ry), uz - (double)(z0 + rz)};
-        double w[2][P], dw[2][P]; // x and y weights; the z weights are made plane by plane
+        // x and y weights (the z weights are made plane by plane).  The spline is even, so the weight of node P-1-v at
+        // offset f is the weight of node v at 1 - f (and its derivative the negative): half of the coefficient table
+        // serves all nodes, which keeps the table in scalar registers instead of spilling it.
+        double w[2][P], dw[2][P];
 #pragma unroll
-        for (int d = 0; d < 2; d++)
+        for (int d = 0; d < 2; d++) {
+            const double g = 1.0 - f[d];
 #pragma unroll
-            for (int v = 0; v < P; v++) {
+            for (int v = 0; v < P / 2; v++) {
                 w[d][v] = piece_eval<P>(sp.piece[v], f[d]);
+                w[d][P - 1 - v] = piece_eval<P>(sp.piece[v], g);
                 dw[d][v] = piece_eval<P - 1>(sp.dpiece[v], f[d]);
+                dw[d][P - 1 - v] = -piece_eval<P - 1>(sp.dpiece[v], g);
             }
+        }
         const double *__restrict__ b0 = blk + (rz * R + ry) * R + (cellx - x0);
         double gx = 0, gy = 0, gz = 0;
 #pragma unroll 1
