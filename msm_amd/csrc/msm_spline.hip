@@ -236,8 +236,14 @@ __global__ __launch_bounds__(1024) void k_anterp_cols(TileSrc S, SplineParams sp
             double *rec_mine = stage + lane * REC;
             rec_mine[0] = lfx;
             rec_mine[1] = lfy;
+            {   // the spline is even: node P-1-cc at offset f weighs what node cc weighs at 1 - f (half the coefficient table)
+                const double lgz = 1.0 - lfz;
 #pragma unroll
-            for (int cc = 0; cc < P; cc++) rec_mine[2 + cc] = ptl.w * piece_eval<P>(sp.piece[cc], lfz);
+                for (int cc = 0; cc < P / 2; cc++) {
+                    rec_mine[2 + cc] = ptl.w * piece_eval<P>(sp.piece[cc], lfz);
+                    rec_mine[2 + P - 1 - cc] = ptl.w * piece_eval<P>(sp.piece[cc], lgz);
+                }
+            }
             rec_mine[2 + P] = __hiloint2double(0, dx + KX * dy);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
