@@ -180,6 +180,9 @@ enum {
 };
 void msm_amd_set_mode(int mode);
 int msm_amd_get_mode(void);
+/* msmperiodic(), msmPeriodicRunner() and msm3d() keep the plan of their last call (stencils and device buffers) and
+ * reuse it when the next call needs the same one; this frees it. */
+void msm_amd_release_cached_plan(void);
 /* quiet != 0 suppresses the stencil / grid-charge dumps msmperiodic() prints in literal mode (msmPeriodic.c:600-610,723-733) */
 void msm_amd_set_quiet(int quiet);
 

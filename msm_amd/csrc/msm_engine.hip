@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "msm_amd.h"
@@ -1118,6 +1119,36 @@ static void write_acc_file(const char *name, int N, const double *f) { // msmPer
     fclose(fp);
 }
 
+// The drop-in entry points keep their last plan (stencils, every device buffer) between calls: a caller that evaluates
+// the same system again and again - a time-stepping loop around msmperiodic() - builds it once.  One plan, replaced when
+// a call needs a different one; the calls are serialised (the reference is not re-entrant either: msmPeriodic.c writes
+// fixed file names).
+namespace {
+struct PlanCache {
+    std::mutex mu;
+    msm_amd_handle *h = nullptr;
+    msm_amd_plan_desc d;
+    bool literal = false;
+} g_plan_cache;
+}
+static int cached_plan(const msm_amd_plan_desc &d, bool literal, msm_amd_handle **out) { // g_plan_cache.mu is held
+    PlanCache &c = g_plan_cache;
+    if (c.h && c.literal == literal && !memcmp(&c.d, &d, sizeof(d))) { *out = c.h; return MSM_AMD_OK; }
+    if (c.h) { msm_amd_destroy(c.h); c.h = nullptr; }
+    const int rc = create_impl(&d, literal, 0, nullptr, out);
+    if (rc) return rc;
+    c.h = *out; c.d = d; c.literal = literal;
+    return MSM_AMD_OK;
+}
+static void drop_cached_plan() { // g_plan_cache.mu is held
+    if (g_plan_cache.h) msm_amd_destroy(g_plan_cache.h);
+    g_plan_cache.h = nullptr;
+}
+extern "C" void msm_amd_release_cached_plan(void) {
+    std::lock_guard<std::mutex> lock(g_plan_cache.mu);
+    drop_cached_plan();
+}
+
 extern "C" msm_stats msmperiodic(int N, double *r, double *q, int p, double abar, int mu, double *uappr, double *fappr,
                                  double Ax, double Ay, double Az) {
     msm_stats S;
@@ -1139,10 +1170,11 @@ extern "C" msm_stats msmperiodic(int N, double *r, double *q, int p, double abar
     d.acc_convention = literal ? MSM_AMD_ACC_LITERAL : MSM_AMD_ACC_GRADIENT;
     S.cputime_initialization = now_s() - t0;
     t0 = now_s();
+    std::lock_guard<std::mutex> cache_lock(g_plan_cache.mu);
     msm_amd_handle *h = nullptr;
-    rc = create_impl(&d, literal, 0, nullptr, &h);
+    rc = cached_plan(d, literal, &h);
     if (rc) { fprintf(stderr, "msmperiodic: %s\n", msm_amd_last_error()); return S; }
-    S.cputime_stencill = now_s() - t0; // stencil generation dominates plan creation
+    S.cputime_stencill = now_s() - t0; // stencil generation dominates plan creation (nothing when the plan was kept)
     const HostPlan &hp = h->hp;
     const int L = d.L;
 
@@ -1220,7 +1252,7 @@ extern "C" msm_stats msmperiodic(int N, double *r, double *q, int p, double abar
     hipFree(dr); hipFree(dq); hipFree(dfs); hipFree(dfl);
     if (!ok) {
         fprintf(stderr, "msmperiodic: %s\n", msm_amd_last_error());
-        msm_amd_destroy(h);
+        drop_cached_plan();
         return S;
     }
     if (literal && !g_quiet) { // msmPeriodic.c:723-733
@@ -1249,8 +1281,7 @@ extern "C" msm_stats msmperiodic(int N, double *r, double *q, int p, double abar
         S.netcharge = qs;
         S.netgridcharge[0] = gs;
     }
-    msm_amd_destroy(h);
-    S.cputime_total = now_s() - t_total;
+    S.cputime_total = now_s() - t_total; // the plan stays for the next call (msm_amd_release_cached_plan frees it)
     return S;
 }
 
@@ -1277,13 +1308,14 @@ extern "C" msm_stats msm3d(int N, double *r, double *q, int p, double hgrid, dou
     int rc = msm_amd_plan_open(N, lo, hi, p, mu, hgrid, a, 0, &d);
     if (rc) { fprintf(stderr, "msm3d: %s\n", msm_amd_last_error()); return S; }
     double t0 = now_s();
+    std::lock_guard<std::mutex> cache_lock(g_plan_cache.mu);
     msm_amd_handle *h = nullptr;
-    rc = create_impl(&d, false, 0, nullptr, &h);
+    rc = cached_plan(d, false, &h);
     if (rc) { fprintf(stderr, "msm3d: %s\n", msm_amd_last_error()); return S; }
     S.cputime_stencill = now_s() - t0;
     double en[MSM_AMD_U_COUNT];
     rc = msm_amd_eval_host(h, r, q, fappr, en);
-    if (rc) { fprintf(stderr, "msm3d: %s\n", msm_amd_last_error()); msm_amd_destroy(h); return S; }
+    if (rc) { fprintf(stderr, "msm3d: %s\n", msm_amd_last_error()); drop_cached_plan(); return S; }
     const int L = d.L;
     S.L = L; S.h = hgrid; S.hx = h->hp.hl[0][0]; S.hy = h->hp.hl[0][1]; S.hz = h->hp.hl[0][2];
     S.a = a; S.aL = std::ldexp(a, L - 1); S.alpha = a / hgrid;
@@ -1300,8 +1332,7 @@ extern "C" msm_stats msm3d(int N, double *r, double *q, int p, double hgrid, dou
     S.potential_total = en[MSM_AMD_U_TOTAL];
     if (uappr) *uappr = S.potential_total;
     { double qs = 0.0; for (int i = 0; i < N; i++) qs += q[i]; S.netcharge = qs; }
-    msm_amd_destroy(h);
-    S.cputime_total = now_s() - t_total;
+    S.cputime_total = now_s() - t_total; // the plan stays for the next call (msm_amd_release_cached_plan frees it)
     return S;
 }
 

@@ -414,6 +414,30 @@ def test_dropin_msmperiodic_matches_reference(msm, name):
     assert rel_rms(f, lit["facc"].reshape(-1, 3), floor) < TOL
 
 
+def test_dropin_keeps_its_plan(msm):
+    """msmperiodic() reuses the plan of its last call when the next call needs the same one, builds a new one when it
+    does not, and gives the same numbers either way."""
+    lib = msm.load()
+    N, A = 6000, (1.0, 1.0, 1.0)
+    r, q = O.neutral_system(N, A, seed=12)
+    out = []
+    for k in range(3):
+        if k == 2:
+            lib.msm_amd_release_cached_plan()
+        st, u, f, _ = msm.msmperiodic(r.copy(), q, 4, 4.0, 10, A, mode=msm.capi.MODE_SCALABLE)
+        out.append((u, f.copy(), st.cputime_stencill))
+    assert out[0][0] == out[1][0] == out[2][0]
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][1], out[2][1])
+    assert out[1][2] < 0.25 * out[0][2]          # the second call built nothing
+    r2, q2 = O.neutral_system(5000, A, seed=13)   # a different system: a different plan
+    st, u2, f2, _ = msm.msmperiodic(r2.copy(), q2, 4, 4.0, 10, A, mode=msm.capi.MODE_SCALABLE)
+    eng = msm.Engine(msm.plan_auto(5000, A, 4, 10, 4.0, 0))
+    en, acc = eng.eval_host(r2, q2)
+    assert abs(u2 - en[6]) <= 1e-12 * np.abs(en[:6]).max() and rel_rms(f2, acc) < 1e-12
+    eng.close()
+    lib.msm_amd_release_cached_plan()
+
+
 def test_dropin_stagewise_literal(msm, torch):
     """Literal mode stage by stage against the literal mirror: grid charges, edir, etop, fshort, flong."""
     for name in ("changaN64", "CsClN16", "changaN512"):
