@@ -87,7 +87,7 @@ class SlabRank:
             g.manual_seed(7 + rank)
             self.delta = (torch.rand(self.r.shape, generator=g, dtype=torch.float64, device=dev) - 0.5) * margin
             self.sign = 1.0
-        self._pending = self._energies = None
+        self._pending = self._pending_work = self._energies = None
 
     def exchange(self):
         """Particle migration and halo refresh after the owned particles have moved (self.r[:n_own] rewritten by the
@@ -200,13 +200,17 @@ class SlabRank:
         s = self.sums.clone()
         if self._host_staged():
             s = s.cpu()
-        self.dist.all_reduce(s)
-        self._pending, self._energies = s, None
+        # asynchronous: the kernels of the next evaluation do not wait for this collective, only a reader of the energies does
+        work = self.dist.all_reduce(s, async_op=True)
+        self._pending, self._pending_work, self._energies = s, work, None
         return self.last_energies if want_energies else None
 
     @property
     def last_energies(self):
         if self._energies is None and self._pending is not None:
+            if self._pending_work is not None:
+                self._pending_work.wait()
+                self._pending_work = None
             sums = self._pending.cpu().numpy().copy()
             sums[2] /= self.world          # the Fourier term is replicated on every rank: the all-reduce added it W times
             self._energies = self.eng.combine_energies(sums)

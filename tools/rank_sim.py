@@ -12,7 +12,7 @@ class FakeWork:
 class FakeDist:
     def get_backend(self): return "nccl"
     def all_gather_into_tensor(self, out, inp, async_op=False): return FakeWork()
-    def all_reduce(self, t): return None
+    def all_reduce(self, t, async_op=False): return None
 
 N = 1000000; p = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 W = int(sys.argv[1])
