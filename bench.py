@@ -70,12 +70,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path in msm_amd)")
+    # MSM_AMD_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices,
+    # collectives staged through the host): a functional check, never a measurement
+    backend = os.environ.get("MSM_AMD_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend=backend)
 
     N, p, mu, abar = args.particles, args.order, 10, 4.0
     A = (1.0, 1.0, 1.0)
@@ -115,7 +123,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     energies = stepper.last_energies
@@ -167,7 +175,8 @@ def main():
                                    "abar=4, mu=10, grid %s, %d levels + Fourier top (kmax=%d)"
                                    % (N, p, "x".join(str(m) for m in desc.M), desc.L, desc.kmax),
                        "particles": N, "order": p, "levels": desc.L, "grid": list(desc.M),
-                       "parallelism": "single GPU" if world == 1 else "z-slabs x%d, level-0 charge all-gather" % world},
+                       "parallelism": "single GPU" if world == 1 else "z-slabs x%d, level-0 charge all-gather" % world,
+                       **({} if backend == "nccl" else {"rehearsal": "ranks share devices, %s collectives through the host: not a measurement" % backend})},
             "roofline": {"kernel": "k_pair_clusters_filtered (short-range pair sum)", "bound": "mfma", "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                          "traffic": traffic, "kernel_ms": pair_s * 1e3,
