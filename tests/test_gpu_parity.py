@@ -834,7 +834,7 @@ def test_command_line_drivers(msm, tmp_path):
     argv, same stdout (the potential with %20.15e), same msm.pot / msm.acc files, on a file in the reference's format."""
     import os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = [os.path.join(root, "drivers", n) for n in ("msmPeriodic", "ewaldClassical")]
+    exe = [os.path.join(root, "drivers", n) for n in ("msmPeriodic", "ewaldClassical", "nonperiodic")]
     if not all(os.path.exists(e) for e in exe):   # normally built beforehand by __graft_entry__.build()
         subprocess.run(["make", "-C", os.path.join(root, "msm_amd", "csrc"), "driver"], capture_output=True, timeout=300)
     if not all(os.path.exists(e) for e in exe):
@@ -859,3 +859,20 @@ def test_command_line_drivers(msm, tmp_path):
     assert out.returncode == 0, out.stderr
     assert abs(float(out.stdout.strip().split()[-1]) - fe["total"]) <= 1e-11 * abs(fe["total"])
     assert "Classical" in out.stderr
+    # msm/nonperiodic.c: same stdout line as the real program printed for this system; and its MSM form within the method
+    fn = O.golden("nonperiodic_changaN64.json")
+    sn = fn["system"]
+    rn = np.array(sn["r"]).reshape(-1, 3)
+    datan = tmp_path / "changaN64.ini"
+    with open(datan, "w") as f:
+        f.write("%.17g %.17g %.17g\n%d\n" % (sn["L"][0], sn["L"][1], sn["L"][2], sn["N"]))
+        for i in range(sn["N"]):
+            f.write("%.17g %.17g %.17g %.17g\n" % (rn[i, 0], rn[i, 1], rn[i, 2], sn["q"][i]))
+    out = subprocess.run([exe[2], str(datan)], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == "u is %15s" % fn["printed"]
+    h = float((rn.max(axis=0) - rn.min(axis=0)).max() / 4.0)
+    out = subprocess.run([exe[2], str(datan), "6", repr(h), repr(4.0 * h), "10"], cwd=tmp_path, capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert abs(float(out.stdout.strip().split()[-1]) - fn["u"]) < 2e-3 * abs(fn["u"]), (out.stdout, out.stderr)
