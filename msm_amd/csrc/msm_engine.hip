@@ -59,7 +59,7 @@ struct msm_amd_handle {
     double *d_energies = nullptr, *h_energies = nullptr;
     const double *cur_r = nullptr, *cur_q = nullptr;
     // host staging for eval_host
-    double *s_r = nullptr, *s_q = nullptr, *s_acc = nullptr;
+    double *s_r = nullptr, *s_q = nullptr, *s_acc = nullptr, *s_acc2 = nullptr;
     // profiling
     bool profiling = false;
     hipEvent_t ev[T_COUNT + 1];
@@ -304,6 +304,16 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         rc = dalloc(&(ptr), (size_t)(n)); \
         if (rc) { msm_amd_destroy(h); return rc; } \
     } while (0)
+    // inside this function a failed HIP call must also release the handle and what it already owns
+#define HIPCHK_H(call)                                                                                \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);     \
+            msm_amd_destroy(h);                                                                       \
+            return MSM_AMD_EHIP;                                                                      \
+        }                                                                                             \
+    } while (0)
     DA(h->ps_cell, N); DA(h->ps_grid, N); DA(h->order_cell, N); DA(h->order_grid, N); DA(h->bin_of, N); DA(h->slot_idx, N);
     DA(h->ccount, h->ncell); DA(h->cstart, h->ncell + 1); DA(h->arrival, N);
     DA(h->gcount, h->gridg.nbins); DA(h->gstart, h->gridg.nbins + 1);
@@ -333,18 +343,18 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
     for (int l = 0; l < L; l++) {
         const size_t n = (size_t)h->hp.Ml[l][0] * h->hp.Ml[l][1] * h->hp.Ml[l][2];
         DA(h->gq[l], n); DA(h->ge[l], n);
-        HIPCHK(hipMemset(h->gq[l], 0, n * sizeof(double)));
-        HIPCHK(hipMemset(h->ge[l], 0, n * sizeof(double)));
+        HIPCHK_H(hipMemset(h->gq[l], 0, n * sizeof(double)));
+        HIPCHK_H(hipMemset(h->ge[l], 0, n * sizeof(double)));
         const LevelStencil &S = h->hp.K[l];
         DA(h->dK[l], S.v.size()); DA(h->dKt[l], S.v.size());
-        HIPCHK(hipMemcpy(h->dK[l], S.v.data(), S.v.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK_H(hipMemcpy(h->dK[l], S.v.data(), S.v.size() * sizeof(double), hipMemcpyHostToDevice));
         // transposed copy [sy][sx][sz] for the tiled kernel (z taps contiguous)
         std::vector<double> t(S.v.size());
         for (int sz = 0; sz < S.size[2]; sz++)
             for (int sy = 0; sy < S.size[1]; sy++)
                 for (int sx = 0; sx < S.size[0]; sx++)
                     t[((size_t)sy * S.size[0] + sx) * S.size[2] + sz] = S.v[((size_t)sz * S.size[1] + sy) * S.size[0] + sx];
-        HIPCHK(hipMemcpy(h->dKt[l], t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK_H(hipMemcpy(h->dKt[l], t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
         const bool open_top = d.open_boundary && l == L - 1; // applied by k_conv_open from dK
         if (!literal && !open_top && S.size[0] == S.size[1] && S.size[1] == S.size[2] && S.size[0] > 23) {
             // smallest padded width n * s over the cube sizes the kernel is built for; ties go to fewer cubes
@@ -362,7 +372,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
                         sub[cube * bs * bs * bs + ((size_t)(y % bs) * bs + x % bs) * bs + z % bs] = S.v[((size_t)z * W + y) * W + x];
                     }
             DA(h->dKsub[l], sub.size());
-            HIPCHK(hipMemcpy(h->dKsub[l], sub.data(), sub.size() * sizeof(double), hipMemcpyHostToDevice));
+            HIPCHK_H(hipMemcpy(h->dKsub[l], sub.data(), sub.size() * sizeof(double), hipMemcpyHostToDevice));
             h->sub_s[l] = bs;
             h->sub_n[l] = bn;
         }
@@ -386,13 +396,13 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
                             ts[o] = S.v[((size_t)sz * S.size[1] + sy) * S.size[0] + sx] + tf[o];
                         }
                 DA(h->dTsum, nL); DA(h->dTfour, nL);
-                HIPCHK(hipMemcpy(h->dTsum, ts.data(), nL * sizeof(double), hipMemcpyHostToDevice));
-                HIPCHK(hipMemcpy(h->dTfour, tf.data(), nL * sizeof(double), hipMemcpyHostToDevice));
+                HIPCHK_H(hipMemcpy(h->dTsum, ts.data(), nL * sizeof(double), hipMemcpyHostToDevice));
+                HIPCHK_H(hipMemcpy(h->dTfour, tf.data(), nL * sizeof(double), hipMemcpyHostToDevice));
             }
         }
         if (d.open_boundary) DA(h->open_part, (size_t)conv_open_groups(h->hp.Ml[L - 1]) * nL);
-        HIPCHK(hipMemset(h->efour, 0, nL * sizeof(double)));
-        HIPCHK(hipMemcpy(h->dKL, h->hp.KL.v.data(), nL * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK_H(hipMemset(h->efour, 0, nL * sizeof(double)));
+        HIPCHK_H(hipMemcpy(h->dKL, h->hp.KL.v.data(), nL * sizeof(double), hipMemcpyHostToDevice));
         DA(h->tmpA, n0 / 2 + 1); DA(h->tmpB, n0 / 4 + 1);
     }
     h->anterp_tiled = !literal && d.M[0] >= 24 && d.M[1] >= 24 && d.M[2] >= 24;
@@ -407,7 +417,8 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
     DA(h->epart, std::max(h->nepart, cg.max_clusters));
     DA(h->parts, 5 * NPARTS);
     DA(h->d_energies, MSM_AMD_U_COUNT);
-    HIPCHK(hipHostMalloc((void **)&h->h_energies, MSM_AMD_U_COUNT * sizeof(double), hipHostMallocDefault));
+    HIPCHK_H(hipHostMalloc((void **)&h->h_energies, MSM_AMD_U_COUNT * sizeof(double), hipHostMallocDefault));
+#undef HIPCHK_H
 #undef DA
     for (int i = 0; i < T_COUNT; i++) h->last_ms[i] = 0.0;
     *out = h;
@@ -444,7 +455,7 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     hipFree(h->efour); hipFree(h->dKL); hipFree(h->dTsum); hipFree(h->dTfour); hipFree(h->tmpA); hipFree(h->tmpB); hipFree(h->epart); hipFree(h->parts);
     hipFree(h->d_energies);
     if (h->h_energies) hipHostFree(h->h_energies);
-    hipFree(h->s_r); hipFree(h->s_q); hipFree(h->s_acc);
+    hipFree(h->s_r); hipFree(h->s_q); hipFree(h->s_acc); hipFree(h->s_acc2);
     if (h->stream_g) {
         hipStreamSynchronize(h->stream_g);
         hipEventDestroy(h->ev_gfork); hipEventDestroy(h->ev_gjoin);
@@ -1006,13 +1017,21 @@ extern "C" int msm_amd_last_kernel_ms(msm_amd_handle *h, const char *name, doubl
     return MSM_AMD_EINVAL;
 }
 
+// Device copies of host-side particle arrays, sized for the handle's capacity: msm_amd_set_counts may raise N up to
+// it after the first host-pointer evaluation.
 static int ensure_staging(msm_amd_handle *h) {
     if (h->s_r) return MSM_AMD_OK;
     int rc;
-    if ((rc = dalloc(&h->s_r, 3 * (size_t)h->N))) return rc;
-    if ((rc = dalloc(&h->s_q, (size_t)h->N))) return rc;
-    if ((rc = dalloc(&h->s_acc, 3 * (size_t)h->N))) return rc;
+    if ((rc = dalloc(&h->s_r, 3 * (size_t)h->capacity))) return rc;
+    if ((rc = dalloc(&h->s_q, (size_t)h->capacity))) return rc;
+    if ((rc = dalloc(&h->s_acc, 3 * (size_t)h->capacity))) return rc;
     return MSM_AMD_OK;
+}
+// second acceleration array of the literal drop-in path (short-range and grid parts are reported separately)
+[[maybe_unused]] static int ensure_staging2(msm_amd_handle *h) {
+    int rc = ensure_staging(h);
+    if (rc || h->s_acc2) return rc;
+    return dalloc(&h->s_acc2, 3 * (size_t)h->capacity);
 }
 
 extern "C" int msm_amd_eval_host(msm_amd_handle *h, const double *r, const double *q, double *acc, double *energies) {
