@@ -340,6 +340,18 @@ int msm_amd_direct_work_doubles(int N);
 int msm_amd_direct_device(int N, const double *d_r, const double *d_q, int i0, int i1, int acc_convention, double *d_acc,
                           double *d_work, void *stream, double *u);
 
+/* msm_amd_direct_device for callers that cannot allocate (code under HIP graph capture, serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference.  Same kernels and the same bits as
+ * msm_amd_direct_device, but the per-workgroup energy partials (its d_work argument) live in a 64 KiB array inside
+ * the library's code object, one copy per GPU, held until the process ends; the call makes no hipMalloc / hipFree
+ * and does not synchronise.  d_u (device, 1 double) receives the slice energy; d_acc[3 (i1 - i0)] as above; the
+ * device that owns the pointers and the stream must be current.  A slice i1 - i0 beyond
+ * msm_amd_direct_noalloc_max_slice() (4 194 304 particles) is refused with MSM_AMD_ERANGE: split it.  Calls that
+ * overlap on one GPU share the array and race; calls queued on one stream do not. */
+int msm_amd_direct_noalloc_max_slice(void);
+int msm_amd_direct_device_noalloc(int N, const double *d_r, const double *d_q, int i0, int i1, int acc_convention,
+                                  double *d_acc, double *d_u, void *stream);
+
 /* Device-resident Ewald sum: potential d_phi[i1 - i0] and its gradient d_grad[3 (i1 - i0)] (may be NULL) at
  * particles [i0, i1) of the N in d_r/d_q, cell edges A[3].  mode MSM_AMD_EWALD_FULL: nearest image inside rcut
  * (rcut <= half the shortest edge), every |k_d| <= ceil(kcut): the converged sum that accuracy figures are

@@ -134,6 +134,8 @@ SIGNATURES = {
                                        _vp, _vp, _vp, _vp, _dp]),
     "msm_amd_direct_work_doubles": (C.c_int, [C.c_int]),
     "msm_amd_direct_device": (C.c_int, [C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _dp]),
+    "msm_amd_direct_noalloc_max_slice": (C.c_int, []),
+    "msm_amd_direct_device_noalloc": (C.c_int, [C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "msm_amd_last_timings": (C.c_int, [_vp, _dp]),
     "msm_amd_last_kernel_ms": (C.c_int, [_vp, C.c_char_p, _dp]),
     "msm_amd_set_profiling": (None, [_vp, C.c_int]),

@@ -14,6 +14,7 @@
 #include "msm_amd.h"
 
 #include <cstring>
+#include <mutex>
 
 namespace msm {
 
@@ -134,6 +135,66 @@ extern "C" int msm_amd_direct_device(int N, const double *d_r, const double *d_q
             return MSM_AMD_EHIP;
         }
     }
+    return MSM_AMD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// The same sum for callers that cannot allocate (HIP graph capture, serving loops): the per-workgroup energy
+// partials that msm_amd_direct_device keeps in its d_work argument live in a file-scope device array instead.
+// Every GPU holds its own copy of that array at its own address until the process ends; the address is looked up
+// once per device and only that pointer - never the array's name, which on the host is a stand-in - is handed to
+// kernels.  Nothing in the array has to start at zero: k_direct overwrites the partials of every workgroup it
+// launches and k_direct_sum reads exactly those.  Two calls that overlap on one GPU share the array and race.
+// ---------------------------------------------------------------------------
+#define DIR_SCRATCH_BLOCKS 8192 // 64 KiB of partials: slices of up to 8192 * 512 = 4 194 304 particles i
+#define DIR_MAX_DEVICES 64
+static __device__ __align__(256) double scratch[DIR_SCRATCH_BLOCKS];
+static double *g_scratch_ptr[DIR_MAX_DEVICES]; // device address of `scratch` on each GPU, 0 until looked up
+static std::mutex g_scratch_mu;
+
+static int direct_scratch(double **out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DIR_MAX_DEVICES) {
+        set_error("msm_amd_direct_device_noalloc: no current HIP device");
+        return MSM_AMD_ENODEV;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            set_error("msm_amd_direct_device_noalloc: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+            return MSM_AMD_EHIP;
+        }
+        g_scratch_ptr[dev] = (double *)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return MSM_AMD_OK;
+}
+
+extern "C" int msm_amd_direct_noalloc_max_slice(void) { return DIR_SCRATCH_BLOCKS * DIR_THREADS * DIR_IPT; }
+
+extern "C" int msm_amd_direct_device_noalloc(int N, const double *d_r, const double *d_q, int i0, int i1, int acc_convention,
+                                             double *d_acc, double *d_u, void *stream) {
+    if (N < 1 || !d_r || !d_q || !d_acc || !d_u || i0 < 0 || i1 > N || i0 >= i1) {
+        set_error("msm_amd_direct_device_noalloc: bad argument");
+        return MSM_AMD_EINVAL;
+    }
+    const long nblk = ((long)i1 - i0 + DIR_THREADS * DIR_IPT - 1) / (DIR_THREADS * DIR_IPT);
+    if (nblk > DIR_SCRATCH_BLOCKS) {
+        set_error("msm_amd_direct_device_noalloc: a slice of %d particles exceeds the built-in scratch (at most %d); "
+                  "split the slice or use msm_amd_direct_device with a work buffer", i1 - i0,
+                  DIR_SCRATCH_BLOCKS * DIR_THREADS * DIR_IPT);
+        return MSM_AMD_ERANGE;
+    }
+    double *part = nullptr;
+    const int rc = direct_scratch(&part);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_direct, dim3((unsigned)nblk), dim3(DIR_THREADS), 0, st, d_r, d_q, N, i0, i1, acc_convention, d_acc, part);
+    hipLaunchKernelGGL(k_direct_sum, dim3(1), dim3(256), 0, st, part, (int)nblk, d_u);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("direct sum launch failed: %s", hipGetErrorString(e)); return MSM_AMD_EHIP; }
     return MSM_AMD_OK;
 }
 
