@@ -97,7 +97,7 @@ def main():
         stepper = SingleGpu(torch, eng, r_all, q_all, dev)
     else:
         from msm_amd.slab import SlabRank
-        stepper = SlabRank(torch, dist, msm_amd, desc, r_all, q_all, rank, world, local_rank)
+        stepper = SlabRank(torch, dist, msm_amd, desc, r_all, q_all, rank, world, local_rank, perturb=True)
         eng = stepper.eng
         if args.pair_variant >= 0:
             eng.set_option("pair_variant", args.pair_variant)

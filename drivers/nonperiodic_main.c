@@ -16,7 +16,10 @@ int main(int argc, char *argv[]) {
         printf("Usage: %s datafile [p h a mu]\n", argv[0]);
         return 1;
     }
-    data_read(argv[1], &q, &r, &N, &Lx, &Ly, &Lz);
+    if (data_read(argv[1], &q, &r, &N, &Lx, &Ly, &Lz)) {
+        fprintf(stderr, "%s\n", msm_amd_last_error());
+        return 1;
+    }
     for (i = 0; i < N; i++) q[i] = 1.0;
     f = (double *)calloc(3 * (size_t)N, sizeof(double));
     if (argc == 2) {

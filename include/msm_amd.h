@@ -44,6 +44,14 @@ extern "C" {
 #endif
 #define VERYLARGENUMBER 1e30
 
+/* The rest of what msm/msmLibrary.h gives a program that includes it (:18-20 TAUP4 / TAUP4D / ERFBETA, :113-149
+ * MasterBaseFunction with the cubic and quintic B-spline pieces and their derivatives, :152-153 JN, :156-185 OMEGA):
+ * generated from this library's own routines by tools/gen_tables.cpp.  The unmodified msmPeriodic.c / msmExpected.c
+ * use them.  A translation unit that wants only the prototypes defines MSM_AMD_NO_TABLES first. */
+#ifndef MSM_AMD_NO_TABLES
+#include "msm_tables.h"
+#endif
+
 /* replaces struct Parameters, msm/msmLibrary.h:22-30 (unused by the reference itself) */
 typedef struct Parameters {
     double abar;
@@ -183,6 +191,8 @@ int msm_amd_get_mode(void);
 /* msmperiodic(), msmPeriodicRunner() and msm3d() keep the plan of their last call (stencils and device buffers) and
  * reuse it when the next call needs the same one; this frees it. */
 void msm_amd_release_cached_plan(void);
+/* number of plans those three entry points have built in this process (a call that reuses the kept plan adds nothing) */
+long msm_amd_plan_builds(void);
 /* quiet != 0 suppresses the stencil / grid-charge dumps msmperiodic() prints in literal mode (msmPeriodic.c:600-610,723-733) */
 void msm_amd_set_quiet(int quiet);
 

@@ -93,6 +93,7 @@ SIGNATURES = {
     "msm_amd_set_mode": (None, [C.c_int]),
     "msm_amd_get_mode": (C.c_int, []),
     "msm_amd_release_cached_plan": (None, []),
+    "msm_amd_plan_builds": (C.c_long, []),
     "msm_amd_set_stencil_backend": (None, [C.c_int]),
     "msm_amd_get_stencil_backend": (C.c_int, []),
     "msm_amd_set_quiet": (None, [C.c_int]),

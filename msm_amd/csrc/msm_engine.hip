@@ -50,6 +50,7 @@ struct msm_amd_handle {
     double *efour = nullptr, *dKL = nullptr, *tmpA = nullptr, *tmpB = nullptr;
     double *dTsum = nullptr, *dTfour = nullptr; // coarsest-level + Fourier stencils as offset tables (both span one period)
     int opt_top_fused = 1;
+    LevelStencil lit_part[2]; // literal mode: gamma / erf terms of the level-0 stencil (diagnostic energies), built on first use
     double *open_part = nullptr; // open boundaries: partial sums of the coarsest level's all-pairs convolution
     int opt_sort_two_level = 1; // creation-time choice (MSM_AMD_SORT=0 in the environment selects the sort with global counters)
     // reductions
@@ -79,6 +80,7 @@ struct msm_amd_handle {
     int *tile_used = nullptr;
     bool anterp_tiled = false;
     int opt_anterp_tiled = 1;
+    SplineOpts sopt; // A/B choices of the tile kernels
     // second stream: the grid pipeline runs beside the list build and the pair kernel
     double *energies_alias = nullptr; // device-visible host slot the energies of the evaluation in flight go to
     hipStream_t stream_b = nullptr;
@@ -502,10 +504,10 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "conv_tiled")) { h->opt_conv_tiled = value; return MSM_AMD_OK; }
     if (!strcmp(key, "conv_small")) { h->opt_conv_small = value; return MSM_AMD_OK; }
     if (!strcmp(key, "anterp_tiled")) { h->opt_anterp_tiled = value; return MSM_AMD_OK; }
-    if (!strcmp(key, "interp_threads")) { if (value >= 64 && value <= 512 && value % 64 == 0) { interp_threads = value; return MSM_AMD_OK; } }
-    if (!strcmp(key, "anterp_cols_waves")) { if (value == 0 || value == 4 || value == 8 || value == 16) { anterp_cols_waves = value; return MSM_AMD_OK; } }
-    if (!strcmp(key, "anterp_cols_order4")) { anterp_cols_order4 = value != 0; return MSM_AMD_OK; }
-    if (!strcmp(key, "anterp_cols")) { anterp_cols_enabled = value != 0; return MSM_AMD_OK; } // process-wide A/B switch
+    if (!strcmp(key, "interp_threads")) { if (value >= 64 && value <= 512 && value % 64 == 0) { h->sopt.interp_threads = value; return MSM_AMD_OK; } }
+    if (!strcmp(key, "anterp_cols_waves")) { if (value == 0 || value == 4 || value == 8 || value == 16) { h->sopt.anterp_cols_waves = value; return MSM_AMD_OK; } }
+    if (!strcmp(key, "anterp_cols_order4")) { h->sopt.anterp_cols_order4 = value != 0; return MSM_AMD_OK; }
+    if (!strcmp(key, "anterp_cols")) { h->sopt.anterp_cols = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "overlap")) { h->opt_overlap = value; return MSM_AMD_OK; }
     if (!strcmp(key, "top_fused")) { h->opt_top_fused = value; return MSM_AMD_OK; }
     if (!strcmp(key, "grid_streams")) { h->opt_grid_streams = value; return MSM_AMD_OK; }
@@ -600,7 +602,7 @@ extern "C" int msm_amd_stage_pairs(msm_amd_handle *h, double *d_acc) {
 extern "C" int msm_amd_stage_anterpolate(msm_amd_handle *h) {
     if (!h || !h->cur_r) { set_error("stage_anterpolate: bin first"); return MSM_AMD_EINVAL; }
     if (!(h->anterp_tiled && h->opt_anterp_tiled &&
-          launch_anterp_tiled(h->stream, tile_source(h), h->sp, h->tiles, h->tile_scratch, h->tile_used, h->gq[0]))) {
+          launch_anterp_tiled(h->stream, tile_source(h), h->sp, h->tiles, h->tile_scratch, h->tile_used, h->gq[0], h->sopt))) {
         ensure_grid_binned(h);
         launch_anterp(h->stream, h->ps_grid, h->gstart, h->sp, h->gq[0]);
     }
@@ -806,7 +808,7 @@ extern "C" int msm_amd_stage_interpolate(msm_amd_handle *h, double *d_acc) {
     // literal: grid index = node + p/2 - 1 (msmPeriodic.c:1136-1151)
     const int shift = h->hp.literal ? h->hp.d.p / 2 - 1 : 0;
     if (h->anterp_tiled && h->opt_anterp_tiled) {
-        launch_interp_tiled(h->stream, tile_source(h), h->sp, h->tiles, h->ge[0], d_acc);
+        launch_interp_tiled(h->stream, tile_source(h), h->sp, h->tiles, h->ge[0], d_acc, h->sopt);
     } else {
         ensure_grid_binned(h);
         launch_interp(h->stream, h->ps_grid, h->order_grid, h->N, h->sp, h->ge[0], shift, d_acc);
@@ -1028,7 +1030,7 @@ static int ensure_staging(msm_amd_handle *h) {
     return MSM_AMD_OK;
 }
 // second acceleration array of the literal drop-in path (short-range and grid parts are reported separately)
-[[maybe_unused]] static int ensure_staging2(msm_amd_handle *h) {
+static int ensure_staging2(msm_amd_handle *h) {
     int rc = ensure_staging(h);
     if (rc || h->s_acc2) return rc;
     return dalloc(&h->s_acc2, 3 * (size_t)h->capacity);
@@ -1150,18 +1152,24 @@ struct PlanCache {
     bool literal = false;
 } g_plan_cache;
 }
+static long g_plan_builds = 0; // plans the drop-in entry points have built so far (guarded by g_plan_cache.mu)
 static int cached_plan(const msm_amd_plan_desc &d, bool literal, msm_amd_handle **out) { // g_plan_cache.mu is held
     PlanCache &c = g_plan_cache;
     if (c.h && c.literal == literal && !memcmp(&c.d, &d, sizeof(d))) { *out = c.h; return MSM_AMD_OK; }
     if (c.h) { msm_amd_destroy(c.h); c.h = nullptr; }
     const int rc = create_impl(&d, literal, 0, nullptr, out);
     if (rc) return rc;
+    g_plan_builds++;
     c.h = *out; c.d = d; c.literal = literal;
     return MSM_AMD_OK;
 }
 static void drop_cached_plan() { // g_plan_cache.mu is held
     if (g_plan_cache.h) msm_amd_destroy(g_plan_cache.h);
     g_plan_cache.h = nullptr;
+}
+extern "C" long msm_amd_plan_builds(void) {
+    std::lock_guard<std::mutex> lock(g_plan_cache.mu);
+    return g_plan_builds;
 }
 extern "C" void msm_amd_release_cached_plan(void) {
     std::lock_guard<std::mutex> lock(g_plan_cache.mu);
@@ -1293,14 +1301,25 @@ extern "C" msm_stats msmperiodic(int N, double *r, double *q, int p, double abar
 
     // literal mode: stage by stage, so that the two acceleration parts can be reported separately (msm.acclong, msm.accshort)
     std::vector<double> fs(3 * (size_t)N), fl(3 * (size_t)N), g0((size_t)d.M[0] * d.M[1] * d.M[2]);
-    double *dr = nullptr, *dq = nullptr, *dfs = nullptr, *dfl = nullptr;
-    bool ok = dalloc(&dr, 3 * (size_t)N) == 0 && dalloc(&dq, (size_t)N) == 0 && dalloc(&dfs, 3 * (size_t)N) == 0 &&
-              dalloc(&dfl, 3 * (size_t)N) == 0;
+    // the handle's staging buffers (kept with the plan), every HIP call checked: a failed copy must not come back as
+    // energies and forces of garbage
+    bool ok = ensure_staging2(h) == MSM_AMD_OK;
+    double *dr = h->s_r, *dq = h->s_q, *dfs = h->s_acc, *dfl = h->s_acc2;
+    auto hip_ok = [&](hipError_t e, const char *what) {
+        if (e == hipSuccess) return true;
+        set_error("msmperiodic: %s failed: %s", what, hipGetErrorString(e));
+        return false;
+    };
     if (ok) {
-        hipMemcpy(dr, r, 3 * (size_t)N * sizeof(double), hipMemcpyHostToDevice);
-        hipMemcpy(dq, q, (size_t)N * sizeof(double), hipMemcpyHostToDevice);
-        hipMemset(dfl, 0, 3 * (size_t)N * sizeof(double));
-        auto tick = [&](double &slot, int rc_) { hipStreamSynchronize(h->stream); slot = now_s() - t0; t0 = now_s(); return rc_; };
+        ok = hip_ok(hipMemcpy(dr, r, 3 * (size_t)N * sizeof(double), hipMemcpyHostToDevice), "copy of r") &&
+             hip_ok(hipMemcpy(dq, q, (size_t)N * sizeof(double), hipMemcpyHostToDevice), "copy of q") &&
+             hip_ok(hipMemset(dfl, 0, 3 * (size_t)N * sizeof(double)), "clearing the grid part");
+        auto tick = [&](double &slot, int rc_) {
+            if (!rc_ && !hip_ok(hipStreamSynchronize(h->stream), "stream synchronisation")) rc_ = MSM_AMD_EHIP;
+            slot = now_s() - t0;
+            t0 = now_s();
+            return rc_;
+        };
         double tbin;
         t0 = now_s();
         ok = ok && !tick(tbin, msm_amd_stage_bin(h, dr, dq));
@@ -1309,13 +1328,10 @@ extern "C" msm_stats msmperiodic(int N, double *r, double *q, int p, double abar
         ok = ok && !tick(S.cputime_interpolation, msm_amd_stage_interpolate(h, dfl));
         ok = ok && !tick(S.cputime_short_range, msm_amd_stage_pairs(h, dfs));
         ok = ok && !tick(S.cputime_potential_long, msm_amd_stage_energies(h, en));
-        if (ok) {
-            hipMemcpy(fs.data(), dfs, fs.size() * sizeof(double), hipMemcpyDeviceToHost);
-            hipMemcpy(fl.data(), dfl, fl.size() * sizeof(double), hipMemcpyDeviceToHost);
-            msm_amd_copy_grid(h, MSM_AMD_GRID_Q, 0, g0.data());
-        }
+        ok = ok && hip_ok(hipMemcpy(fs.data(), dfs, fs.size() * sizeof(double), hipMemcpyDeviceToHost), "copy of the short-range part") &&
+             hip_ok(hipMemcpy(fl.data(), dfl, fl.size() * sizeof(double), hipMemcpyDeviceToHost), "copy of the grid part") &&
+             msm_amd_copy_grid(h, MSM_AMD_GRID_Q, 0, g0.data()) == MSM_AMD_OK;
     }
-    hipFree(dr); hipFree(dq); hipFree(dfs); hipFree(dfl);
     if (!ok) {
         fprintf(stderr, "msmperiodic: %s\n", msm_amd_last_error());
         drop_cached_plan();
@@ -1324,6 +1340,35 @@ extern "C" msm_stats msmperiodic(int N, double *r, double *q, int p, double abar
     if (literal && !g_quiet) { // msmPeriodic.c:723-733
         printf("grid charge at first level\n");
         for (size_t i = 0; i < g0.size(); i++) printf("%25.16e\n", g0[i]);
+    }
+    if (literal && !g_quiet) {
+        // msmPeriodic.c:1334-1341: the grid energy of the gamma term and of the erf term of the level-0 kernel on their
+        // own, 1/2 q0 . (sl_part{1,2} * q0) with the same grid-to-grid loop; the stencils are built on the host once
+        // per plan, the two convolutions run on the GPU
+        if (h->lit_part[0].v.empty()) build_literal_parts(h->hp, h->lit_part[0], h->lit_part[1]);
+        const size_t n0 = g0.size();
+        double part_u[2] = {0.0, 0.0};
+        bool pok = true;
+        for (int k = 0; k < 2 && pok; k++) {
+            const LevelStencil &P = h->lit_part[k];
+            std::vector<double> e(n0);
+            double *dKp = nullptr, *dEp = nullptr;
+            pok = dalloc(&dKp, P.v.size()) == MSM_AMD_OK && dalloc(&dEp, n0) == MSM_AMD_OK &&
+                  hip_ok(hipMemcpy(dKp, P.v.data(), P.v.size() * sizeof(double), hipMemcpyHostToDevice), "copy of a part stencil");
+            if (pok) {
+                launch_conv_literal(h->stream, h->gq[0], dKp, h->hp.Ml[0], P.size, P.first, dEp);
+                pok = hip_ok(hipStreamSynchronize(h->stream), "part convolution") &&
+                      hip_ok(hipMemcpy(e.data(), dEp, n0 * sizeof(double), hipMemcpyDeviceToHost), "copy of a part potential");
+            }
+            hipFree(dKp); hipFree(dEp);
+            if (pok) for (size_t i = 0; i < n0; i++) part_u[k] += 0.5 * e[i] * g0[i];
+        }
+        if (pok) {
+            printf("%-20s : %25.16e\n", "    ulong_real_g1", part_u[0]);
+            printf("%-20s : %25.16e\n", "    ulong_real_gLR", part_u[1]);
+        } else {
+            fprintf(stderr, "msmperiodic: %s\n", msm_amd_last_error());
+        }
     }
     S.potential_short_real = en[MSM_AMD_U_SHORT_REAL];
     S.potential_short_self = en[MSM_AMD_U_SHORT_SELF];

@@ -295,7 +295,7 @@ extern "C" long long msm_amd_ewald_work_doubles(int N, double kcut, int ni) {
 extern "C" int msm_amd_ewald_device(int N, const double *d_r, const double *d_q, const double A[3], double alpha, double rcut,
                                     double kcut, int mode, int i0, int i1, double *d_phi, double *d_grad, double *d_work,
                                     void *stream, double *u5) {
-    if (N < 1 || !d_r || !d_q || !A || !d_phi || !d_work || i0 < 0 || i1 > N || i0 >= i1 || !(alpha > 0) || !(rcut > 0) ||
+    if (N < 1 || !d_r || !d_q || !A || !d_phi || !d_work || i0 < 0 || i1 > N || i0 >= i1 || !(alpha > 0) || !(rcut > 0 || (rcut == 0 && mode == MSM_AMD_EWALD_LITERAL)) ||
         !(kcut >= 0) || kcut > 200 || !(A[0] > 0 && A[1] > 0 && A[2] > 0) || (mode != MSM_AMD_EWALD_FULL && mode != MSM_AMD_EWALD_LITERAL)) {
         set_error("msm_amd_ewald_device: bad argument");
         return MSM_AMD_EINVAL;

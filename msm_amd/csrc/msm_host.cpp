@@ -218,13 +218,21 @@ void level_geometry(const HostPlan &hp, int l, LevelStencil &S, LevelGeom &G) {
     }
 }
 
-static void build_level(HostPlan &hp, int l) {
-    LevelStencil &S = hp.K[l];
+// part = 0: the level's kernel; 1 / 2: the two terms of the coarsest level's kernel on their own, gamma(r/a_l)/a_l and
+// erf(beta r)/r, summed over the same images without a support radius (they decay like 1/r) - the stencils behind the
+// reference's diagnostic energies ulong_real_g1 / ulong_real_gLR (sl_part1 / sl_part2, msmPeriodic.c:555-590)
+static void build_level_into(const HostPlan &hp, int l, int part, LevelStencil &S) {
     LevelGeom geo;
     level_geometry(hp, l, S, geo);
     const int W = geo.W;
     const int *ext = geo.ext, *R = geo.R, *amax = geo.amax;
-    const double rcut = geo.rcut;
+    const double rcut = part ? 1e300 : geo.rcut;
+    const double al_ = std::ldexp(hp.d.a, l), beta_ = hp.d.beta;
+    auto kernel = [&](double r) {
+        if (part == 1) return gamma_eval(r / al_, hp.d.p) / al_;
+        if (part == 2) return (r < DBL_EPSILON) ? 2.0 * beta_ / std::sqrt(PI) : std::erf(beta_ * r) / r;
+        return level_kernel(hp, l, r);
+    };
     // The image sum is even in every coordinate (the images come in +- pairs), so it is evaluated once per
     // (|nx|, |ny|, |nz|) and copied to the other octants: an eighth of the kernel evaluations.
     std::vector<double> T((size_t)(amax[0] + 1) * (amax[1] + 1) * (amax[2] + 1));
@@ -243,7 +251,7 @@ static void build_level(HostPlan &hp, int l) {
                             const double dx = x - hp.d.A[0] * px;
                             if (std::fabs(dx) > rcut) continue;
                             const double rr = std::sqrt(dx * dx + dy * dy + dz * dz);
-                            if (rr <= rcut) g += level_kernel(hp, l, rr);
+                            if (rr <= rcut) g += kernel(rr);
                         }
                     }
                 }
@@ -285,6 +293,12 @@ static void build_level(HostPlan &hp, int l) {
                 for (int k = -W; k <= W; k++) s += w[std::abs(k)] * T2[((size_t)(nz + k + W) * S.size[1] + ny) * S.size[0] + nx];
                 S.v[((size_t)nz * S.size[1] + ny) * S.size[0] + nx] = s;
             }
+}
+static void build_level(HostPlan &hp, int l) { build_level_into(hp, l, 0, hp.K[l]); }
+
+void build_literal_parts(const HostPlan &hp, LevelStencil &g1_part, LevelStencil &gLR_part) {
+    build_level_into(hp, hp.d.L - 1, 1, g1_part);
+    build_level_into(hp, hp.d.L - 1, 2, gLR_part);
 }
 
 // Fourier top level on the coarsest grid (msm/msmPeriodic.c:265-391, msm/msmSimple.c:1181-1246):

@@ -65,6 +65,9 @@ struct StencilBackend {
 // fills Ml/hl/khat/wprime/J/K/KL/cvec/chi... from hp.d (+ hp.literal); stencils by `be` when given, else on the host
 int build_host_plan(HostPlan &hp, const StencilBackend *be = nullptr);
 
+// literal mode: the coarsest level's stencil split into its gamma term and its erf term (host; msmPeriodic.c:555-590)
+void build_literal_parts(const HostPlan &hp, LevelStencil &g1_part, LevelStencil &gLR_part);
+
 // stencil builders on the current HIP device (msm_stencil.hip)
 const StencilBackend *device_stencil_backend();
 

@@ -130,14 +130,17 @@ struct TileSrc {
     int cluster_order;
     double scale[3];     // slot coordinate -> grid units
 };
-extern bool anterp_cols_enabled;
-extern int anterp_cols_waves;
-extern int interp_threads;
-extern bool anterp_cols_order4;
+// A/B choices of the tile kernels, kept per handle
+struct SplineOpts {
+    int interp_threads = 256;       // threads of a tile workgroup of the interpolation kernel (multiple of 64, at most 512)
+    int anterp_cols_waves = 0;      // waves per tile workgroup of the column kernel: 4, 8, 16, or 0 = by the share of owned planes
+    bool anterp_cols_order4 = false; // the column kernel at order 4 too
+    bool anterp_cols = true;        // register accumulation per column (cluster order, columns up to 2 x 2 cells)
+};
 bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, double *scratch,
-                         int *tile_used, double *grid);
+                         int *tile_used, double *grid, const SplineOpts &opt);
 void launch_interp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, const double *egrid,
-                         double *acc);
+                         double *acc, const SplineOpts &opt);
 void launch_interp(hipStream_t st, const double4 *ps_grid, const int *order, int N, const SplineParams &sp,
                    const double *egrid, int index_shift, double *acc);
 // one axis of the separable restriction: out has the axis halved.  J[0..p/2]

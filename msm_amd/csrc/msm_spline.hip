@@ -429,28 +429,22 @@ __global__ __launch_bounds__(512) void k_interp_tiles(TileSrc S, SplineParams sp
     }
 }
 
-int interp_threads = 256;        // threads of a tile workgroup of the interpolation kernel (multiple of 64, at most 512)
-
 void launch_interp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, const double *egrid,
-                         double *acc) {
+                         double *acc, const SplineOpts &opt) {
     // gridDim.y > 1 shares a tile's particles between workgroups; measured slower even for a rank that owns a thin
     // slab (every workgroup stages the tile's block of potentials again), so one workgroup per tile it is
     const int ns = 1;
-    const int nthreads = interp_threads;
+    const int nthreads = opt.interp_threads;
     if (sp.p == 4) hipLaunchKernelGGL((k_interp_tiles<4>), dim3(tl.ntiles, ns), dim3(nthreads), 0, st, S, sp, tl, egrid, acc);
     else hipLaunchKernelGGL((k_interp_tiles<6>), dim3(tl.ntiles, ns), dim3(nthreads), 0, st, S, sp, tl, egrid, acc);
 }
 
-int anterp_cols_waves = 0;        // waves per tile workgroup of the column kernel: 4, 8, 16, or 0 = by the share of owned planes
-bool anterp_cols_order4 = false;  // A/B: the column kernel at order 4 too
-bool anterp_cols_enabled = true; // A/B switch: register accumulation per column (cluster order, columns up to 2 x 2 cells)
-
 bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, double *scratch,
-                         int *tile_used, double *grid) {
+                         int *tile_used, double *grid, const SplineOpts &opt) {
     const size_t n = (size_t)sp.M[0] * sp.M[1] * sp.nz;
     const int gb = (int)((n + 255) / 256);
     static bool attr4 = false, attr6 = false;
-    if ((sp.p == 6 || anterp_cols_order4) && S.cluster_order && S.cg.kx >= 1 && S.cg.kx <= 2 && S.cg.ky >= 1 && S.cg.ky <= 2 && anterp_cols_enabled) {
+    if ((sp.p == 6 || opt.anterp_cols_order4) && S.cluster_order && S.cg.kx >= 1 && S.cg.kx <= 2 && S.cg.ky >= 1 && S.cg.ky <= 2 && opt.anterp_cols) {
         // order 6, columns of at most 2 x 2 cells: sums kept in registers (at order 4 a particle's 64 nodes are one LDS
         // update of a full wave, which is faster)
         const int R = AT + sp.p - 1;
@@ -467,7 +461,7 @@ bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &s
             done = true;
             // 4 waves per tile fill the chip when every tile has particles; a rank that owns a thin slab has few busy
             // tiles and finishes sooner with 8 (more runs at a time, at the price of more flush phases)
-            const int nw = anterp_cols_waves ? anterp_cols_waves : (2 * sp.nz <= sp.M[2] ? 8 : 4);
+            const int nw = opt.anterp_cols_waves ? opt.anterp_cols_waves : (2 * sp.nz <= sp.M[2] ? 8 : 4);
             const int rec = (2 + sp.p + 1 + 1) / 2 * 2;
             const size_t dyn = sizeof(double) * ((size_t)(R * R * R + 1) / 2 * 2 + (size_t)nw * 64 * rec);
             hipLaunchKernelGGL(k, dim3(tl.ntiles), dim3(64 * nw), dyn, st, S, sp, tl, scratch, tile_used);

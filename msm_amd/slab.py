@@ -56,10 +56,15 @@ def halo_width(desc, margin=0.0):
 
 class SlabRank:
     """One rank of a slab-decomposed evaluation.  `engine_factory(desc)` returns an object with the Engine
-    interface (tests inject a CPU stand-in to exercise the partition and collective logic without a GPU)."""
+    interface (tests inject a CPU stand-in to exercise the partition and collective logic without a GPU).
+
+    perturb=True is a benchmarking device only (bench.py, tools/rank_sim.py): every step() then displaces the held
+    positions by up to margin/2, alternating in sign, so that no step repeats the previous one, and the halo is
+    widened by `margin` to keep every partner of a displaced particle.  The default leaves the caller's positions
+    alone."""
 
     def __init__(self, torch, dist, msm_amd, desc, r_all, q_all, rank, world, local_rank=0, margin=2e-4,
-                 engine_factory=None, perturb=True, headroom=1.02):
+                 engine_factory=None, perturb=False, headroom=1.02):
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
         self.z0, self.nz = slab_planes(desc.M[2], world, rank)
         own, hal = select_slab(r_all, desc.A[2], desc.M[2], world, rank, halo_width(desc, margin if perturb else 0.0))

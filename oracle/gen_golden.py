@@ -66,6 +66,40 @@ def read_acc(path):
     return out
 
 
+def parse_periodic_stdout(lines):
+    """What msmPeriodic prints (msmPeriodic.c:600-610 stencil dump, :723-733 grid charges, :1340-1341 and
+    msmLibrary.c:290-376 labelled values) -> {"stencil0", "gridcharge0", "scalars", "stats"}."""
+    i = 0
+    stencil = []
+    grid = []
+    scalars = {}
+    stats = {}
+    while i < len(lines):
+        ln = lines[i]
+        if ln.startswith("Stencil["):
+            i += 1
+            while i < len(lines) and " x " in lines[i]:
+                stencil.append(float(lines[i].split()[-1]))
+                i += 1
+            continue
+        if ln.startswith("grid charge at first level"):
+            i += 1
+            while i < len(lines) and ":" not in lines[i] and lines[i].strip():
+                grid.append(float(lines[i].split()[0]))
+                i += 1
+            continue
+        m = re.match(r"^(.{0,20}?)\s*:\s*([-+0-9.eEnaif]+)\s*$", ln)
+        if m:
+            scalars[m.group(1).strip()] = float(m.group(2))
+        elif len(ln) > 31 and ln[30] == " ":
+            key = ln[:30].strip()
+            val = ln[31:].strip()
+            if key and key not in ("chi", "cvecx", "cvecy", "cvecz"):
+                stats[key] = val
+        i += 1
+    return {"stencil0": stencil, "gridcharge0": grid, "scalars": scalars, "stats": stats}
+
+
 def run_periodic(name, p=4, mu=10, abar=4):
     src = os.path.join(DATA, "benchmark_%s.txt" % name)
     tmp = tempfile.mkdtemp(prefix="msmref_")
@@ -75,38 +109,7 @@ def run_periodic(name, p=4, mu=10, abar=4):
                              cwd=tmp, capture_output=True, text=True, check=True)
         lines = res.stdout.splitlines()
         fx = {"program": "msmPeriodic", "args": [name, p, mu, abar], "system": read_system(src)}
-        i = 0
-        stencil = []
-        grid = []
-        scalars = {}
-        stats = {}
-        while i < len(lines):
-            ln = lines[i]
-            if ln.startswith("Stencil["):
-                i += 1
-                while i < len(lines) and " x " in lines[i]:
-                    stencil.append(float(lines[i].split()[-1]))
-                    i += 1
-                continue
-            if ln.startswith("grid charge at first level"):
-                i += 1
-                while i < len(lines) and ":" not in lines[i] and lines[i].strip():
-                    grid.append(float(lines[i].split()[0]))
-                    i += 1
-                continue
-            m = re.match(r"^(.{0,20}?)\s*:\s*([-+0-9.eEnaif]+)\s*$", ln)
-            if m:
-                scalars[m.group(1).strip()] = float(m.group(2))
-            elif len(ln) > 31 and ln[30] == " ":
-                key = ln[:30].strip()
-                val = ln[31:].strip()
-                if key and key not in ("chi", "cvecx", "cvecy", "cvecz"):
-                    stats[key] = val
-            i += 1
-        fx["stencil0"] = stencil
-        fx["gridcharge0"] = grid
-        fx["scalars"] = scalars
-        fx["stats"] = stats
+        fx.update(parse_periodic_stdout(lines))
         fx["potential"] = float(lines[-1])
         fx["acc"] = read_acc(os.path.join(tmp, "msm.acc"))
         fx["acclong"] = read_acc(os.path.join(tmp, "msm.acclong"))

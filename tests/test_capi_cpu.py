@@ -270,3 +270,134 @@ def test_real_msmsimple_runs_on_our_cache_files(msm, tmp_path):
     for k in ("ulong_real", "ulong_four", "utotal"):
         assert abs(got[k] - sc[k]) <= 2e-10 * max(abs(sc[k]), 1e-3 * scale), (k, got[k], sc[k])
     assert got["time_stencilKl"] < 0.05 * max(sc["time_stencilKl"], 1e-3) or got["time_stencilKl"] < 0.01
+
+
+# ---------------------------------------------------------------------------
+# the header as the reference's drivers see it
+# ---------------------------------------------------------------------------
+def test_generated_tables_header_is_current(tmp_path):
+    """include/msm_tables.h (TAUP4 / TAUP4D / ERFBETA, B-spline pieces, JN, OMEGA: msm/msmLibrary.h:18-20,113-185) is
+    what tools/gen_tables.cpp prints from the library's own spline_pieces / two_scale / compute_wprime / gamma_poly."""
+    import subprocess
+    exe = tmp_path / "gen_tables"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "msm_amd", "csrc"),
+                    "-DMSM_AMD_NO_TABLES", os.path.join(ROOT, "tools", "gen_tables.cpp"),
+                    os.path.join(ROOT, "msm_amd", "csrc", "msm_host.cpp"), "-o", str(exe)], check=True, timeout=300)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    assert out == open(os.path.join(ROOT, "include", "msm_tables.h")).read()
+
+
+def test_tables_header_values(msm, tmp_path):
+    """The generated header through a C compiler: the spline pieces against the Cox-de Boor recursion of
+    msmPeriodic.c:10-19 and a finite difference, JN against binomials, OMEGA against the library's omega' (which
+    tests/test_oracle_golden.py pins to the reference's table), TAUP4 / TAUP4D against the series of msmPeriodic.c:22-34."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text(r'''
+#include "msmLibrary.h"
+double piece(int p, int der, int v, double t) {
+    const struct MasterBaseFunction *b = p == 4 ? (der ? &CubicBSplineD : &CubicBSpline) : (der ? &QuinticBSplineD : &QuinticBSpline);
+    return b->p == p ? b->region[v](t) : -1e300;
+}
+double jn(int i, int j) { return JN[i][j]; }
+double omega(int i, int j) { return OMEGA[i][j]; }
+double taup4(double x) { return TAUP4(x); }
+double taup4d(double x) { return TAUP4D(x); }
+double erfbeta(double b, double x) { return ERFBETA(b, x); }
+''')
+    so = tmp_path / "t.so"
+    subprocess.run(["gcc", "-O1", "-std=c99", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(so), "-lm"],
+                   check=True, timeout=120)
+    t = C.CDLL(str(so))
+    for f in (t.piece, t.jn, t.omega, t.taup4, t.taup4d, t.erfbeta):
+        f.restype = C.c_double
+    t.piece.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double]
+    t.jn.argtypes = t.omega.argtypes = [C.c_int, C.c_int]
+    t.taup4.argtypes = t.taup4d.argtypes = [C.c_double]
+    t.erfbeta.argtypes = [C.c_double, C.c_double]
+
+    def bspline(k, u):   # cardinal B-spline of order k on [0, k)
+        if k == 1:
+            return 1.0 if 0 <= u < 1 else 0.0
+        return u / (k - 1) * bspline(k - 1, u) + (k - u) / (k - 1) * bspline(k - 1, u - 1.0)
+    for p in (4, 6):
+        for v in range(p):
+            lo = p / 2 - 1 - v            # region[v] covers [lo, lo + 1]
+            for f in np.linspace(0.01, 0.99, 23):
+                x = lo + f
+                assert abs(t.piece(p, 0, v, x) - bspline(p, x + p / 2)) < 5e-15
+                d = bspline(p - 1, x + p / 2) - bspline(p - 1, x + p / 2 - 1)   # B_p' = B_{p-1}(u) - B_{p-1}(u - 1)
+                assert abs(t.piece(p, 1, v, x) - d) < 5e-15
+    from math import comb, erf, pi, sqrt
+    for i, p in enumerate((4, 6)):
+        for j in range(6):
+            assert t.jn(i, j) == (comb(p, p // 2 + j) / 2 ** (p - 1) if j <= p // 2 else 0.0)
+        w = msm.HostPlan(msm.plan_explicit(64, (1.0, 1.0, 1.0), (4, 4, 4), p, 10, 1, 1.0, 2.5, 5)).wprime()
+        assert len(w) == 10 + p // 2 + 1
+        for j in range(14):
+            assert t.omega(i, j) == (w[j] if j < len(w) else 0.0)
+        ref = O.wprime(p, 10)
+        assert np.abs(np.array([t.omega(i, j) for j in range(len(ref))]) - ref).max() < 3e-15 * abs(ref[0])
+    for x in np.linspace(0.0, 1.0, 11):
+        y = x * x - 1.0
+        series = 1.0 - y / 2 + 3.0 * y * y / 8 - 5.0 * y ** 3 / 16      # binomial series of (1 + y)^(-1/2), 4 terms
+        assert abs(t.taup4(x) - series) < 4e-16 * 2.1875
+        dseries = (-0.5 + 0.75 * y - 15.0 * y * y / 16) * 2 * x
+        assert abs(t.taup4d(x) - dseries) < 1e-15 * 4.375
+    assert t.taup4(0.0) == 35.0 / 16
+    assert t.erfbeta(1.3, 0.0) == 2.0 * 1.3 / sqrt(pi) and abs(t.erfbeta(1.3, 0.5) - erf(0.65) / 0.5) < 1e-16
+
+
+REF_SRC = "/root/reference/msm"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="the reference's sources are not on this machine")
+def test_unmodified_reference_drivers_build_against_include_and_link_the_library(tmp_path):
+    """msmExpected.c, nonperiodic.c, ewaldClassical.c and msmPeriodic.c, compiled where they lie with -Iinclude (so
+    that "msmLibrary.h" / "ewaldClassical.h" resolve to this repository's headers) and linked to libmsm_amd.so instead
+    of msmLibrary.o, reproduce what the real builds printed (fixtures).  They need no GPU: msmPeriodic.c brings its
+    own msmperiodic() and takes chooseM / choosebetaNew / choosekmax / chooseL / short_range_periodic / data_read /
+    print_stats / the linked list from the library."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from gen_golden import parse_periodic_stdout
+    exe = {}
+    for name in ("msmExpected", "nonperiodic", "ewaldClassical", "msmPeriodic"):
+        exe[name] = tmp_path / name
+        res = subprocess.run(["gcc", "-O2", "-std=c99", "-I" + os.path.join(ROOT, "include"), "-o", str(exe[name]),
+                              os.path.join(REF_SRC, name + ".c"), "-L" + os.path.join(ROOT, "msm_amd"), "-lmsm_amd",
+                              "-Wl,-rpath," + os.path.join(ROOT, "msm_amd"), "-lm"], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+
+    def data(name):
+        return os.path.join(REF_SRC, "data", "benchmark_%s.txt" % name)
+
+    def run(name, *args):
+        res = subprocess.run([str(exe[name])] + [str(a) for a in args], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-500:]
+        return res
+    for sysname in ("NaClN8", "changaN8", "CsClN16"):
+        fx = O.golden("msmExpected_%s.json" % sysname)
+        got = {}
+        for ln in run("msmExpected", data(sysname), *fx["args"][1:]).stdout.splitlines():
+            m = re.match(r"^(.{0,20}?)\s*:\s*([-+0-9.eEnaif]+)\s*$", ln)
+            if m:
+                got[m.group(1).strip()] = float(m.group(2))
+        assert set(got) == set(fx["scalars"])
+        scale = max(abs(v) for k, v in fx["scalars"].items() if k.startswith("("))
+        for k, v in fx["scalars"].items():
+            assert abs(got[k] - v) <= 1e-13 * max(abs(v), scale if "u" in k else 0.0), (sysname, k, got[k], v)
+    for sysname in ("CsClN2", "NaClN8"):
+        fx = O.golden("msmPeriodic_%s.json" % sysname)
+        res = run("msmPeriodic", data(sysname), 4, 10, 4)
+        got = parse_periodic_stdout(res.stdout.splitlines())
+        assert got["scalars"] == fx["scalars"] and got["stencil0"] == fx["stencil0"] and got["gridcharge0"] == fx["gridcharge0"]
+        assert set(got["stats"]) == set(fx["stats"])
+        for k, v in fx["stats"].items():     # print_stats (msmLibrary.c:290-376) comes from the library here
+            assert k.startswith("time") or got["stats"][k] == v, (sysname, k, got["stats"][k], v)
+        assert float(res.stdout.splitlines()[-1]) == fx["potential"]
+    fx = O.golden("nonperiodic_changaN8.json")
+    assert run("nonperiodic", data("changaN8")).stdout.strip() == "u is %15s" % fx["printed"]
+    fx = O.golden("ewaldClassical_NaClN8.json")
+    assert float(run("ewaldClassical", data("NaClN8"), *fx["args"][1:]).stdout.strip().split()[-1]) == fx["total"]

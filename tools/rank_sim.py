@@ -18,7 +18,7 @@ N = 1000000; p = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 W = int(sys.argv[1])
 r, q = make_system(N, 20261113)
 desc = msm_amd.plan_auto(N, (1.0, 1.0, 1.0), p, 10, 4.0, 0)
-s = SlabRank(torch, FakeDist(), msm_amd, desc, r, q, W // 2, W, 0)
+s = SlabRank(torch, FakeDist(), msm_amd, desc, r, q, W // 2, W, 0, perturb=True)
 for kv in filter(None, (sys.argv[3] if len(sys.argv) > 3 else "").split(",")):   # engine options: key=value,key=value
     k, v = kv.split("=")
     s.eng.set_option(k, int(v))
