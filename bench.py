@@ -177,7 +177,7 @@ def main():
                        "particles": N, "order": p, "levels": desc.L, "grid": list(desc.M),
                        "parallelism": "single GPU" if world == 1 else "z-slabs x%d, level-0 charge all-gather" % world,
                        **({} if backend == "nccl" else {"rehearsal": "ranks share devices, %s collectives through the host: not a measurement" % backend})},
-            "roofline": {"kernel": "k_pair_clusters_filtered (short-range pair sum)", "bound": "mfma", "achieved": achieved,
+            "roofline": {"kernel": "k_pair_clusters_filtered (short-range pair sum)", "bound": "valu_fp64", "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                          "traffic": traffic, "kernel_ms": pair_s * 1e3,
                          "note": "FP64 vector FMA bound (the FP64 MFMA peak is the same 78.6 TF); algorithmic flops = "

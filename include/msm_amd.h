@@ -19,6 +19,7 @@
 #ifndef MSM_AMD_H
 #define MSM_AMD_H
 
+#include <stddef.h>
 #include <stdio.h>
 
 #ifdef __cplusplus
@@ -295,6 +296,54 @@ int msm_amd_stage_raw_sums(msm_amd_handle *h, double *host_out5);
 void *msm_amd_raw_sums_device_ptr(msm_amd_handle *h);
 /* host arithmetic: energies from raw sums that were added over all ranks */
 int msm_amd_combine_energies(msm_amd_handle *h, const double sums[5], double energies[MSM_AMD_U_COUNT]);
+
+/* ---- one evaluation of a slab rank, collectives included (the host stays in C) ----
+ * The exchange steps of the z-slab decomposition go through a small table of collectives, so that the same C code runs
+ * over RCCL (msm_amd_rccl_create below: ncclAllGather / ncclSend + ncclRecv / ncclAllReduce on the handle's own
+ * streams), over MPI on device pointers, or over whatever a test harness plugs in.  Every function queues its work
+ * on `stream` (a hipStream_t) and returns 0 on success; buffers are device pointers of doubles.  No counterpart in the
+ * reference, which is serial and contains no collective call. */
+typedef struct msm_amd_collectives {
+    int rank, world;
+    void *ctx;
+    /* recv[k * count .. (k + 1) * count) <- the `count` doubles of rank k; send may be recv + rank * count (in place) */
+    int (*all_gather)(void *ctx, const double *send, double *recv, size_t count, void *stream);
+    /* buf[0 .. count) <- sum over the ranks, in place */
+    int (*all_reduce_sum)(void *ctx, double *buf, size_t count, void *stream);
+    /* neighbour exchange of `count` doubles each way: send_up goes to rank `up` (= rank + 1, periodic), send_down to rank
+     * `down`; recv_from_down receives what `down` sent up, recv_from_up what `up` sent down.  With two ranks up == down. */
+    int (*halo_exchange)(void *ctx, const double *send_up, const double *send_down, double *recv_from_down,
+                         double *recv_from_up, size_t count, int up, int down, void *stream);
+} msm_amd_collectives;
+
+/* RCCL implementation of the table (librccl.so is loaded on first use; MSM_AMD_ENODEV if it cannot be).
+ * msm_amd_rccl_unique_id: rank 0 calls it and hands the 128 bytes to the other ranks by any means (a file, MPI_Bcast,
+ * torch.distributed); every rank then calls msm_amd_rccl_create with the device it will run on current. */
+int msm_amd_rccl_unique_id(char id[128]);
+int msm_amd_rccl_create(const char id[128], int rank, int world, msm_amd_collectives **out);
+void msm_amd_rccl_destroy(msm_amd_collectives *c);
+
+/* How the level-0 charge planes reach the ranks that need them. */
+enum {
+    MSM_AMD_SLAB_AUTO = 0,      /* halo exchange when it is possible and moves less than the all-gather */
+    MSM_AMD_SLAB_ALLGATHER = 1, /* every rank gets the whole level-0 charge grid (one collective; coarse levels solved redundantly) */
+    MSM_AMD_SLAB_HALO = 2       /* p/2 + (stencil half width) planes from each z neighbour, level-1 charges all-gathered;
+                                   needs L >= 2, an even number of owned planes, and halos that fit the neighbours' slabs */
+};
+/* What msm_amd_slab_step would do for this handle and world size under `mode` (one of the two concrete values), or a
+ * negative error when `mode` asks for a halo exchange the plan cannot do. */
+int msm_amd_slab_exchange_mode(msm_amd_handle *h, int world, int mode);
+
+/* One evaluation of the particles this rank holds (msm_amd_set_counts: the first n_owned of them owned, the rest halo
+ * copies): sort -> [pair sum on the handle's stream] beside [anterpolation of the owned planes -> exchange -> grid levels ->
+ * interpolation on a second stream] -> raw sums -> all-reduce.  d_acc[3 n_total] receives the accelerations of the
+ * owned particles.  The call queues everything and returns; the reduced sums stay on the device until
+ * msm_amd_slab_energies reads them.  coll == NULL (or world == 1 with a full-grid handle): no exchange, the handle
+ * must own every plane. */
+int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *coll, const double *d_r, const double *d_q, double *d_acc,
+                      int mode);
+/* synchronises and turns the reduced sums of the last msm_amd_slab_step into (A)..(F) and the total */
+int msm_amd_slab_energies(msm_amd_handle *h, const msm_amd_collectives *coll, double energies[MSM_AMD_U_COUNT]);
 
 /* device pointers / copies of internal state (for the slab all-gather and the tests) */
 enum { MSM_AMD_GRID_Q = 0, MSM_AMD_GRID_E = 1, MSM_AMD_GRID_EFOUR = 2 };

@@ -67,6 +67,21 @@ class MsmStats(C.Structure):
                 ("potential_long_fourier", C.c_double)]
 
 
+# struct msm_amd_collectives: the exchange steps of a slab rank as a table of functions (stream = hipStream_t)
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+HALO_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                               C.c_int, C.c_void_p)
+
+
+class Collectives(C.Structure):
+    """struct msm_amd_collectives"""
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("ctx", C.c_void_p), ("all_gather", ALL_GATHER_FN),
+                ("all_reduce_sum", ALL_REDUCE_FN), ("halo_exchange", HALO_EXCHANGE_FN)]
+
+
+SLAB_AUTO, SLAB_ALLGATHER, SLAB_HALO = 0, 1, 2
+
 # every symbol include/msm_amd.h declares: name -> (restype, argtypes)
 _vp = C.c_void_p
 _vpp = C.POINTER(C.c_void_p)
@@ -115,6 +130,12 @@ SIGNATURES = {
     "msm_amd_stage_raw_sums": (C.c_int, [_vp, _dp]),
     "msm_amd_raw_sums_device_ptr": (_vp, [_vp]),
     "msm_amd_combine_energies": (C.c_int, [_vp, _dp, _dp]),
+    "msm_amd_rccl_unique_id": (C.c_int, [C.c_char_p]),
+    "msm_amd_rccl_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.POINTER(Collectives))]),
+    "msm_amd_rccl_destroy": (None, [C.POINTER(Collectives)]),
+    "msm_amd_slab_exchange_mode": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "msm_amd_slab_step": (C.c_int, [_vp, C.POINTER(Collectives), _vp, _vp, _vp, C.c_int]),
+    "msm_amd_slab_energies": (C.c_int, [_vp, C.POINTER(Collectives), _dp]),
     "msm_amd_grid_device_ptr": (_vp, [_vp, C.c_int, C.c_int]),
     "msm_amd_grid_dims": (C.c_int, [_vp, C.c_int, _ip]),
     "msm_amd_copy_grid": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),

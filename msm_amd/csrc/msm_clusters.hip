@@ -759,10 +759,16 @@ __global__ __launch_bounds__(256) void k_pair_clusters_filtered(ClusterGeom g, C
                                                                 double *__restrict__ acc, double *__restrict__ epart) {
     __shared__ double4 queue[4][CLQ_CAP];
     const int lane = threadIdx.x & 63, ii = lane >> 3, jj = lane & 7;
-    const int blk = xcd_remap(blockIdx.x, gridDim.x);
-    const int icl = __builtin_amdgcn_readfirstlane(blk * 4 + (threadIdx.x >> 6));
-    if (icl >= g.max_clusters) return;
+    // A workgroup takes a run of consecutive clusters (4 per step, one per wave).  Launched with one workgroup per
+    // step this is the plain one-wave-per-cluster kernel; launched with a few workgroups per CU it leaves room on
+    // every CU for the kernels of another stream (the grid branch of a slab step), at the same speed: two waves per
+    // SIMD already keep the FP64 pipe busy.  Runs are handed out so that an XCD gets neighbouring clusters.
+    const int nsteps = (g.max_clusters + 3) / 4, per = (nsteps + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int step0 = xcd_remap(blockIdx.x, gridDim.x) * per, step1 = min(nsteps, step0 + per);
     const int ncl = b.clstart[g.ncols];
+    for (int step = step0; step < step1; step++) [&] {
+    const int icl = __builtin_amdgcn_readfirstlane(step * 4 + (threadIdx.x >> 6));
+    if (icl >= g.max_clusters) return;
     if (icl >= ncl) {
         if (lane == 0) epart[icl] = 0.0;
         return;
@@ -877,6 +883,198 @@ __global__ __launch_bounds__(256) void k_pair_clusters_filtered(ClusterGeom g, C
     else walk(L + MID, 1, nd, false, No{}, uh);
     walk(L + S - 1, -1, ns, true, No{}, uh);
     cl_finish(I, pp, jj, icl, 2.0 * u1 + uh, fx, fy, fz, acc, epart, lane);
+    }();
+}
+
+// The list walked at particle granularity, with the survivors sorted into two queues.  Of the particles that come
+// within the cutoff of i's bounding box only 44 % lie within the cutoff of a given particle of i, so more than half of
+// the lanes of k_pair_clusters_filtered evaluate pairs that contribute nothing.  Here the 64 listed particles of a
+// step are tested against the 8 particles of i themselves - squared distances in packed single precision, two
+// particles of i per instruction, against a cutoff widened by more than the rounding of the single-precision
+// coordinates, so that no pair the double-precision arithmetic would keep is lost - and a particle is kept for the
+// lower half of i (its first four particles: the cluster is sorted along z) and / or for the upper half only if it
+// is within the cutoff of a particle of that half.  Each half has its own queue, evaluated with lane = (i of the
+// half, one of 16 queued particles): 22 % fewer particles survive the test, and a survivor is paired only with the
+// half (or halves) it is near.  The exact cutoff test of the pair arithmetic is unchanged, so are the energy
+// bookkeeping and the fixed order of every sum.
+#define CLS_W 16 // queued particles per evaluated group
+#define CLS_U 2  // groups per unrolled step of the pair arithmetic
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int P, bool HALF>
+__global__ __launch_bounds__(256, 4) void k_pair_clusters_split(ClusterGeom g, ClusterBuffers b, PairParams pp, float a2w,
+                                                             double *__restrict__ acc, double *__restrict__ epart) {
+    // a queue entry is stored as two 16-byte halves, (x, y) and (z, q), in separate arrays: 16 consecutive entries of
+    // either array cover the 64 LDS banks exactly once, which is what a 16-lane group of a ds_read_b128 touches
+    __shared__ double2 queue[4][2][2][CLQ_CAP];
+    const int lane = threadIdx.x & 63, hh = lane >> 4, jj = lane & (CLS_W - 1);
+    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int icl = __builtin_amdgcn_readfirstlane(blk * 4 + (threadIdx.x >> 6));
+    if (icl >= g.max_clusters) return;
+    const int ncl = b.clstart[g.ncols];
+    if (icl >= ncl) {
+        if (lane == 0) epart[icl] = 0.0;
+        return;
+    }
+    const int nu = b.n0[icl], ns = b.n1[icl], nd = b.n2[icl];
+    if (nu < 0) return; // list overflow: left to the list-free kernel
+    // this lane's particle of the lower half (A) and of the upper half (B)
+    const LaneI IA = load_lane_i(g, b, pp, icl, hh), IB = load_lane_i(g, b, pp, icl, CL_G / 2 + hh);
+    if (!__ballot(IA.owned || IB.owned)) {
+        if (lane == 0) epart[icl] = 0.0;
+        return;
+    }
+    const int S = g.list_stride, MID = S / 2;
+    const int *__restrict__ L = b.list + (size_t)icl * S;
+    double2 *QA = queue[threadIdx.x >> 6][0][0], *QB = queue[threadIdx.x >> 6][1][0]; // (z, q) halves follow at + CLQ_CAP
+    const double4 nowhere = make_double4(g.far, g.far, g.far, 0.0);
+    // the 8 particles of i in single precision, two to a register pair (same address in every lane)
+    v2f ix[4], iy[4], iz[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double4 p0 = b.ps[(size_t)CL_G * icl + 2 * k], p1 = b.ps[(size_t)CL_G * icl + 2 * k + 1];
+        // a padding slot as i keeps away from the padding slots it would meet as j (as load_lane_i does)
+        const float x0 = b.order[(size_t)CL_G * icl + 2 * k] == CL_DUMMY ? (float)(-2.0 * g.far) : (float)p0.x;
+        const float x1 = b.order[(size_t)CL_G * icl + 2 * k + 1] == CL_DUMMY ? (float)(-2.0 * g.far) : (float)p1.x;
+        ix[k] = (v2f){x0, x1};
+        iy[k] = (v2f){(float)p0.y, (float)p1.y};
+        iz[k] = (v2f){(float)p0.z, (float)p1.z};
+    }
+    int tailA = 0, tailB = 0; // entries waiting in the queues (wave-uniform)
+    double u1A = 0, uhA = 0, fxA = 0, fyA = 0, fzA = 0, u1B = 0, uhB = 0, fxB = 0, fyB = 0, fzB = 0;
+    {   // the cluster's own pairs: particle jj of the cluster against this lane's two particles
+        const double4 own = b.ps[(size_t)CL_G * icl + (jj & (CL_G - 1))];
+        cl_slot<P, true>(IA.x, IA.y, IA.z, own, pp, jj < CL_G && jj != hh, uhA, fxA, fyA, fzA);
+        cl_slot<P, true>(IB.x, IB.y, IB.z, own, pp, jj < CL_G && jj != CL_G / 2 + hh, uhB, fxB, fyB, fzB);
+    }
+
+    auto filter = [&](unsigned ent, double4 p, bool shifted) {
+        if (shifted) {
+            double sx, sy, sz;
+            shift_of_code(g, (int)(ent >> CL_CODE_SHIFT), sx, sy, sz);
+            p.x += sx; p.y += sy; p.z += sz;
+        }
+        const float xf = (float)p.x, yf = (float)p.y, zf = (float)p.z;
+        const v2f X = (v2f){xf, xf}, Y = (v2f){yf, yf}, Z = (v2f){zf, zf};
+        v2f d[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const v2f dx = X - ix[k], dy = Y - iy[k], dz = Z - iz[k];
+            d[k] = dx * dx + dy * dy + dz * dz;
+        }
+        const bool keepA = fminf(fminf(d[0].x, d[0].y), fminf(d[1].x, d[1].y)) < a2w;
+        const bool keepB = fminf(fminf(d[2].x, d[2].y), fminf(d[3].x, d[3].y)) < a2w;
+        const unsigned long long mA = __ballot(keepA), mB = __ballot(keepB);
+        if (keepA) {
+            const int pos = tailA + lane_rank(mA);
+            QA[pos] = make_double2(p.x, p.y);
+            QA[CLQ_CAP + pos] = make_double2(p.z, p.w);
+        }
+        if (keepB) {
+            const int pos = tailB + lane_rank(mB);
+            QB[pos] = make_double2(p.x, p.y);
+            QB[CLQ_CAP + pos] = make_double2(p.z, p.w);
+        }
+        tailA += __popcll(mA);
+        tailB += __popcll(mB);
+        __builtin_amdgcn_wave_barrier();
+    };
+    // pair arithmetic on the complete groups of CLS_W in a queue (and, with `final`, on the incomplete last one)
+    auto drain = [&](auto force_only, double2 *Q, int &tail, const LaneI &I, double &ua, double &fx, double &fy, double &fz,
+                     bool final) {
+        constexpr bool FO = decltype(force_only)::value;
+        const double2 *qr = Q + jj;
+        auto entry = [&](int at) {
+            const double2 xy = qr[at], zq = qr[CLQ_CAP + at];
+            return make_double4(xy.x, xy.y, zq.x, zq.y);
+        };
+        int done = 0;
+        for (; done + CLS_U * CLS_W <= tail; done += CLS_U * CLS_W) {
+            double4 qv[CLS_U];
+#pragma unroll
+            for (int k = 0; k < CLS_U; k++) qv[k] = entry(done + CLS_W * k);
+#pragma unroll
+            for (int k = 0; k < CLS_U; k++) {
+                if (FO) cl_slot_force<P>(I.x, I.y, I.z, qv[k], pp, fx, fy, fz);
+                else cl_slot<P, false>(I.x, I.y, I.z, qv[k], pp, true, ua, fx, fy, fz);
+            }
+        }
+        for (; done + CLS_W <= tail; done += CLS_W) {
+            const double4 q = entry(done);
+            if (FO) cl_slot_force<P>(I.x, I.y, I.z, q, pp, fx, fy, fz);
+            else cl_slot<P, false>(I.x, I.y, I.z, q, pp, true, ua, fx, fy, fz);
+        }
+        const int rem = tail - done;
+        if (final) {
+            if (rem > 0) {
+                const double4 q = jj < rem ? entry(done) : nowhere;
+                if (FO) cl_slot_force<P>(I.x, I.y, I.z, q, pp, fx, fy, fz);
+                else cl_slot<P, false>(I.x, I.y, I.z, q, pp, true, ua, fx, fy, fz);
+            }
+            tail = 0;
+        } else {
+            // the incomplete last group moves to the front (done >= 49 > rem: source and destination are disjoint)
+            if (lane < rem) { Q[lane] = Q[done + lane]; Q[CLQ_CAP + lane] = Q[CLQ_CAP + done + lane]; }
+            tail = rem;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    using Yes = std::true_type;
+    using No = std::false_type;
+
+    // one part of the list, as in k_pair_clusters_filtered: entries fetched 64 at a time, handed out 8 per step (lane
+    // (e, s) loads particle s of entry e), the particles of the next step requested before the current ones are tested
+    const int sub = lane >> 3;
+    const char *__restrict__ psb = (const char *)b.ps + 32 * (lane & 7);
+    auto particle = [&](unsigned ent, bool shifted) { // byte offsets stay below 2^32: checked by the launcher
+        return *(const double4 *)(psb + ((shifted ? ent & (unsigned)CL_JMASK : ent) << 8));
+    };
+    auto walk = [&](const int *__restrict__ base, int dir, int n, bool shifted, auto force_only, double &uaA, double &uaB) {
+        const unsigned pad = (unsigned)g.max_clusters | (shifted ? (unsigned)CL_NOSHIFT << CL_CODE_SHIFT : 0u);
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const unsigned mine = c0 + lane < n ? (unsigned)base[dir * (c0 + lane)] : pad;
+            const int steps = (min(64, n - c0) + CL_G - 1) / CL_G;
+            unsigned ea = __shfl(mine, sub);
+            double4 pa = particle(ea, shifted);
+            for (int k = 0; k < steps; k++) {
+                const unsigned en = __shfl(mine, CL_G * (k + 1) + sub); // lane index taken mod 64; past the end: padding
+                const double4 pn = particle(en, shifted);
+                filter(ea, pa, shifted);
+                if (tailA >= 64) drain(force_only, QA, tailA, IA, uaA, fxA, fyA, fzA, false);
+                if (tailB >= 64) drain(force_only, QB, tailB, IB, uaB, fxB, fyB, fzB, false);
+                ea = en;
+                pa = pn;
+            }
+        }
+        drain(force_only, QA, tailA, IA, uaA, fxA, fyA, fzA, true);
+        drain(force_only, QB, tailB, IB, uaB, fxB, fyB, fzB, true);
+    };
+    walk(L + 1, 1, nu - 1, false, No{}, HALF ? u1A : uhA, HALF ? u1B : uhB);
+    if (HALF) walk(L + MID, 1, nd, false, Yes{}, uhA, uhB);
+    else walk(L + MID, 1, nd, false, No{}, uhA, uhB);
+    walk(L + S - 1, -1, ns, true, No{}, uhA, uhB);
+
+    // sum the CLS_W lanes that share a particle i, write its acceleration and energy share
+    double e = 0.0;
+    auto finish = [&](const LaneI &I, double u, double fx, double fy, double fz) {
+#pragma unroll
+        for (int off = 1; off < CLS_W; off <<= 1) {
+            u += __shfl_xor(u, off);
+            fx += __shfl_xor(fx, off);
+            fy += __shfl_xor(fy, off);
+            fz += __shfl_xor(fz, off);
+        }
+        if (jj == 0 && I.owned) {
+            const double w = pp.convention == MSM_AMD_ACC_FORCE ? -I.q : 1.0;
+            acc[3 * (size_t)I.orig] = w * fx;
+            acc[3 * (size_t)I.orig + 1] = w * fy;
+            acc[3 * (size_t)I.orig + 2] = w * fz;
+            e += 0.5 * I.q * u;
+        }
+    };
+    finish(IA, 2.0 * u1A + uhA, fxA, fyA, fzA);
+    finish(IB, 2.0 * u1B + uhB, fxB, fyB, fzB);
+    e = wave_sum(e);
+    if (lane == 0) epart[icl] = e;
 }
 
 // The same sum for one cluster without a list: the wave enumerates its candidates and evaluates each surviving
@@ -952,9 +1150,10 @@ __global__ __launch_bounds__(256) void k_pair_clusters_overflow(ClusterGeom g, C
 }
 
 void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double *acc,
-                          double *epart, int variant, int n_total, hipEvent_t *ev) {
+                          double *epart, int variant, int n_total, hipEvent_t *ev, int max_wgs) {
     const double a = sqrt(pp.a2);
     const int nblk = (g.max_clusters + 3) / 4;
+    const int nwg = max_wgs > 0 ? std::min(nblk, max_wgs) : nblk; // workgroups of the list-walking kernel (it loops over its share)
     const int half = pp.n_owned >= n_total ? 1 : 0; // every particle owned: pair energies are taken from one side
     if (variant == 1) {
         if (pp.p == 4) hipLaunchKernelGGL((k_pair_clusters_direct<4>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart, half);
@@ -972,10 +1171,24 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
 #define LAUNCH_PF(P, HALF)                                                                                          \
     do {                                                                                                            \
         if (ev) hipEventRecord(ev[0], st);                                                                          \
-        hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF>), dim3(nblk), dim3(256), 0, st, g, b, pp, acc, epart); \
+        hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF>), dim3(nwg), dim3(256), 0, st, g, b, pp, acc, epart); \
         if (ev) hipEventRecord(ev[1], st);                                                                          \
     } while (0)
-    if (variant == 3 && g.max_clusters < (1 << 24)) { // lists walked at particle granularity (32-bit byte offsets)
+    if (variant == 4 && g.max_clusters < (1 << 24)) { // particle granularity, survivors split by the half of i they are near
+        // cutoff of the single-precision test: coordinates up to 2 A (a periodic image) carry 2^-24 relative rounding each
+        double amax = std::max(g.A[0], std::max(g.A[1], g.A[2]));
+        const double eps = 2e-6 * amax / a + 4e-6;
+        const float a2w = (float)(pp.a2 * (1.0 + eps)) * 1.000001f;
+#define LAUNCH_PS(P, HALF)                                                                                               \
+    do {                                                                                                                 \
+        if (ev) hipEventRecord(ev[0], st);                                                                               \
+        hipLaunchKernelGGL((k_pair_clusters_split<P, HALF>), dim3(nblk), dim3(256), 0, st, g, b, pp, a2w, acc, epart);   \
+        if (ev) hipEventRecord(ev[1], st);                                                                               \
+    } while (0)
+        if (pp.p == 4) { if (h) LAUNCH_PS(4, true); else LAUNCH_PS(4, false); }
+        else { if (h) LAUNCH_PS(6, true); else LAUNCH_PS(6, false); }
+#undef LAUNCH_PS
+    } else if (variant == 3 && g.max_clusters < (1 << 24)) { // lists walked at particle granularity (32-bit byte offsets)
         if (pp.p == 4) { if (h) LAUNCH_PF(4, true); else LAUNCH_PF(4, false); }
         else { if (h) LAUNCH_PF(6, true); else LAUNCH_PF(6, false); }
     } else if (pp.p == 4) {

@@ -1,6 +1,8 @@
 // Handle layer + the drop-in msmperiodic()/msmPeriodicRunner() built on it.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -61,6 +63,7 @@ struct msm_amd_handle {
     const double *cur_r = nullptr, *cur_q = nullptr;
     // host staging for eval_host
     double *s_r = nullptr, *s_q = nullptr, *s_acc = nullptr, *s_acc2 = nullptr;
+    double *acc_grid = nullptr; // slab step: the grid part of the accelerations, added to the pair part at the end
     // profiling
     bool profiling = false;
     hipEvent_t ev[T_COUNT + 1];
@@ -89,6 +92,10 @@ struct msm_amd_handle {
     int opt_grid_streams = 0; // measured: slower (1.68 vs 1.65 ms at 1M; the chain of small kernels does not get CUs while the
                               // level-0 convolution runs), and cross-stream waits stalled with 4 processes sharing one GPU
     hipEvent_t ev_fork = nullptr, ev_pairs = nullptr, ev_join = nullptr;
+    int opt_pair_wgs = 512;   // slab step with two streams: workgroups of the pair kernel (2 per CU), so that the grid branch finds room
+    int pair_wgs_now = 0;     // cap in force for the next pair launch (0: one workgroup per four clusters)
+    int opt_slab_overlap = 1; // slab step: the grid branch on a second stream beside the pair sum (0: one stream, for several
+                              // processes sharing one GPU, where cross-stream waits were seen to stall)
     int opt_overlap = 0; // measured: +5 % evaluations/s, but the pair kernel's workgroups starve the large convolution blocks
     int opt_transfer_fused = 4;              // 4: restriction and prolongation tiled through LDS, one launch per level (default); 3: restriction
                                              // only; 0: separable passes; 1, 2: thread per node, slower at every size measured
@@ -457,7 +464,7 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     hipFree(h->efour); hipFree(h->dKL); hipFree(h->dTsum); hipFree(h->dTfour); hipFree(h->tmpA); hipFree(h->tmpB); hipFree(h->epart); hipFree(h->parts);
     hipFree(h->d_energies);
     if (h->h_energies) hipHostFree(h->h_energies);
-    hipFree(h->s_r); hipFree(h->s_q); hipFree(h->s_acc); hipFree(h->s_acc2);
+    hipFree(h->s_r); hipFree(h->s_q); hipFree(h->s_acc); hipFree(h->s_acc2); hipFree(h->acc_grid);
     if (h->stream_g) {
         hipStreamSynchronize(h->stream_g);
         hipEventDestroy(h->ev_gfork); hipEventDestroy(h->ev_gjoin);
@@ -509,6 +516,9 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "anterp_cols_order4")) { h->sopt.anterp_cols_order4 = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "anterp_cols")) { h->sopt.anterp_cols = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "overlap")) { h->opt_overlap = value; return MSM_AMD_OK; }
+    if (!strcmp(key, "slab_overlap")) { h->opt_slab_overlap = value; return MSM_AMD_OK; }
+    if (!strcmp(key, "pair_wgs")) { h->opt_pair_wgs = value; return MSM_AMD_OK; }
+    if (!strcmp(key, "pair_wgs_now")) { h->pair_wgs_now = value; return MSM_AMD_OK; } // A/B: also outside the slab step
     if (!strcmp(key, "top_fused")) { h->opt_top_fused = value; return MSM_AMD_OK; }
     if (!strcmp(key, "grid_streams")) { h->opt_grid_streams = value; return MSM_AMD_OK; }
     if (!strcmp(key, "transfer_fused")) { h->opt_transfer_fused = value; return MSM_AMD_OK; }
@@ -583,7 +593,7 @@ extern "C" int msm_amd_stage_pairs(msm_amd_handle *h, double *d_acc) {
             launch_cluster_sort(h->stream, h->cur_r, h->cur_q, h->N, h->clg, h->clb, h->bin_of, h->arrival, h->slot_idx, h->scan_tmp);
         h->clusters_sorted = true;
         launch_pair_clusters(h->stream, h->clg, h->clb, h->pp, d_acc, h->epart, h->opt_pair_variant - 5, h->N,
-                             h->profiling ? h->ev_pk : nullptr);
+                             h->profiling ? h->ev_pk : nullptr, h->pair_wgs_now);
         h->pk_recorded = h->profiling && h->opt_pair_variant != 6;
         h->nepart = h->clg.max_clusters;
     } else {
@@ -636,10 +646,12 @@ static bool transfer_fused(const msm_amd_handle *h, int l) {
     const long n = (long)h->hp.Ml[l][0] * h->hp.Ml[l][1] * h->hp.Ml[l][2];
     return h->opt_transfer_fused == 1 || (h->opt_transfer_fused == 2 && n <= h->opt_transfer_fused_max);
 }
-static void restrict_level(msm_amd_handle *h, int l, const double *fine, double *coarse) {
+// zc0, nzc: coarse planes to produce (nzc <= 0: all of them); a plane range needs the tiled kernel
+static void restrict_level(msm_amd_handle *h, int l, const double *fine, double *coarse, int zc0 = 0, int nzc = 0) {
     const int p = h->hp.d.p;
     int m0[3] = {h->hp.Ml[l][0], h->hp.Ml[l][1], h->hp.Ml[l][2]};
-    if (h->opt_transfer_fused >= 3) { launch_restrict_tiled(h->stream, fine, coarse, m0, p, h->hp.J); return; }
+    if (nzc <= 0) { zc0 = 0; nzc = m0[2] / 2; }
+    if (h->opt_transfer_fused >= 3 || nzc < m0[2] / 2) { launch_restrict_tiled(h->stream, fine, coarse, m0, p, h->hp.J, zc0, nzc); return; }
     if (transfer_fused(h, l)) { launch_restrict3(h->stream, fine, coarse, m0, p, h->hp.J); return; }
     launch_restrict_axis(h->stream, fine, h->tmpA, m0, 0, p, h->hp.J);
     int m1[3] = {m0[0] / 2, m0[1], m0[2]};
@@ -647,11 +659,13 @@ static void restrict_level(msm_amd_handle *h, int l, const double *fine, double 
     int m2[3] = {m0[0] / 2, m0[1] / 2, m0[2]};
     launch_restrict_axis(h->stream, h->tmpB, coarse, m2, 2, p, h->hp.J);
 }
-static void prolong_level_add(msm_amd_handle *h, int l, const double *coarse, double *fine) {
+// zf0, nzf: fine planes to add to (nzf <= 0: all of them); a plane range needs the tiled kernel
+static void prolong_level_add(msm_amd_handle *h, int l, const double *coarse, double *fine, int zf0 = 0, int nzf = 0) {
     const int p = h->hp.d.p;
-    if (h->opt_transfer_fused == 4) {
+    if (nzf <= 0 || nzf >= h->hp.Ml[l][2]) { zf0 = 0; nzf = h->hp.Ml[l][2]; }
+    if (h->opt_transfer_fused == 4 || nzf < h->hp.Ml[l][2]) {
         int m0[3] = {h->hp.Ml[l][0], h->hp.Ml[l][1], h->hp.Ml[l][2]};
-        launch_prolong_tiled_add(h->stream, coarse, fine, m0, p, h->hp.J);
+        launch_prolong_tiled_add(h->stream, coarse, fine, m0, p, h->hp.J, zf0, nzf);
         return;
     }
     if (transfer_fused(h, l)) {
@@ -729,11 +743,15 @@ static void top_level(msm_amd_handle *h) {
     }
 }
 
-extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
-    if (!h) return MSM_AMD_EINVAL;
+// The grid stage.  halo_coll != NULL: a slab rank in halo mode - level 0 holds the owned charge planes and the halo
+// planes received from the z neighbours only, so the first restriction produces the coarse planes under the owned
+// ones and the level-1 charge grid is completed by an all-gather (queued on the handle's stream) before the chain
+// goes on; the coarser levels are then solved by every rank, being too small to shard.
+static int grid_stage(msm_amd_handle *h, const msm_amd_collectives *halo_coll) {
     const msm_amd_plan_desc &d = h->hp.d;
     const int L = d.L, p = d.p;
     hipStream_t st = h->stream;
+    const bool slab = d.nzplanes < d.M[2];
     // plane ranges to convolve on level 0: everything, except on a slab rank, where the potentials are needed on the
     // owned planes plus p/2 planes either side (interpolation support) and the other planes of ge[0] are left at zero
     std::vector<PlaneRange> fine, coarse;
@@ -775,7 +793,17 @@ extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
         HIPCHK(hipStreamWaitEvent(h->stream_g, h->ev_gfork, 0));
         h->stream = h->stream_g; // the helpers below enqueue on the handle's stream
     }
-    for (int l = 0; l + 1 < L; l++) restrict_level(h, l, h->gq[l], h->gq[l + 1]);
+    for (int l = 0; l + 1 < L; l++) {
+        if (l == 0 && halo_coll) {
+            const size_t plane1 = (size_t)h->hp.Ml[1][0] * h->hp.Ml[1][1];
+            restrict_level(h, 0, h->gq[0], h->gq[1], d.zplane0 / 2, d.nzplanes / 2);
+            const int rc = halo_coll->all_gather(halo_coll->ctx, h->gq[1] + plane1 * (d.zplane0 / 2), h->gq[1],
+                                                 plane1 * (d.nzplanes / 2), (void *)h->stream);
+            if (rc) { set_error("slab step: the all-gather of the level-1 charges failed (%d)", rc); return MSM_AMD_EHIP; }
+            continue;
+        }
+        restrict_level(h, l, h->gq[l], h->gq[l + 1]);
+    }
     if (!two) {
         mark(h, T_CONV);
         std::vector<PlaneRange> all(fine);
@@ -798,9 +826,18 @@ extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
         HIPCHK(hipStreamWaitEvent(st, h->ev_gjoin, 0));
         mark(h, T_PRO);
     }
-    if (L >= 2) prolong_level_add(h, 0, h->ge[1], h->ge[0]);
+    if (L >= 2) {
+        // a slab rank reads the potentials of its own planes and p/2 planes either side only
+        if (slab && d.nzplanes + p < d.M[2]) prolong_level_add(h, 0, h->ge[1], h->ge[0], d.zplane0 - p / 2, d.nzplanes + p);
+        else prolong_level_add(h, 0, h->ge[1], h->ge[0]);
+    }
     HIPCHK(hipGetLastError());
     return MSM_AMD_OK;
+}
+
+extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
+    if (!h) return MSM_AMD_EINVAL;
+    return grid_stage(h, nullptr);
 }
 
 extern "C" int msm_amd_stage_interpolate(msm_amd_handle *h, double *d_acc) {
@@ -900,21 +937,26 @@ static bool can_overlap(const msm_amd_handle *h) {
            h->opt_pair_variant >= 5 && h->pp.convention != MSM_AMD_ACC_LITERAL;
 }
 
+// second stream for the grid branch: highest priority, its workgroups are short-lived and should not queue behind the
+// pair kernel's
+static int ensure_stream_b(msm_amd_handle *h) {
+    if (h->stream_b) return MSM_AMD_OK;
+    int prio_lo = 0, prio_hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIPCHK(hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, prio_hi));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreate(&h->ev_pairs));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    return MSM_AMD_OK;
+}
+
 extern "C" int msm_amd_eval(msm_amd_handle *h, const double *d_r, const double *d_q, double *d_acc, double *energies) {
     if (!h || !d_r || !d_q || !d_acc) { set_error("msm_amd_eval: null argument"); return MSM_AMD_EINVAL; }
     HIPCHK(hipSetDevice(h->device));
     int rc;
     h->pk_recorded = false;
     const bool overlap = can_overlap(h);
-    if (overlap && !h->stream_b) {
-        // highest priority: its workgroups are short-lived and should not queue behind the pair kernel's
-        int prio_lo = 0, prio_hi = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        HIPCHK(hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, prio_hi));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreate(&h->ev_pairs));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    }
+    if (overlap && (rc = ensure_stream_b(h))) return rc;
     mark(h, T_BIN);
     if ((rc = msm_amd_stage_bin(h, d_r, d_q))) return rc;
     if (overlap) {
@@ -999,6 +1041,232 @@ extern "C" int msm_amd_eval_enqueue(msm_amd_handle *h, const double *d_r, const 
     if (host_energies && !alias)
         HIPCHK(hipMemcpyAsync(host_energies, h->d_energies, MSM_AMD_U_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     return MSM_AMD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// one evaluation of a slab rank, collectives included
+// ---------------------------------------------------------------------------
+// planes a rank needs from each z neighbour in halo mode: the interpolation support (p/2) plus the reach of the
+// level-0 stencil; 0 when the stencil spans the whole period (then only the all-gather works)
+static int slab_halo_planes(const msm_amd_handle *h) {
+    const msm_amd_plan_desc &d = h->hp.d;
+    const int S = h->hp.K[0].size[2];
+    if (S >= d.M[2] || !(S & 1)) return 0;
+    return d.p / 2 + (S - 1) / 2;
+}
+
+extern "C" int msm_amd_slab_exchange_mode(msm_amd_handle *h, int world, int mode) {
+    if (!h || world < 1) return MSM_AMD_EINVAL;
+    const msm_amd_plan_desc &d = h->hp.d;
+    const int Mz = d.M[2], nz = d.nzplanes, H = slab_halo_planes(h);
+    const bool can_halo = d.L >= 2 && world >= 2 && H > 0 && nz % 2 == 0 && d.zplane0 % 2 == 0 && H <= nz && nz + 2 * H <= Mz &&
+                          (long)nz * world == Mz && !h->hp.literal && !d.open_boundary;
+    if (mode == MSM_AMD_SLAB_HALO) {
+        if (can_halo) return MSM_AMD_SLAB_HALO;
+        set_error("slab step: a halo exchange needs L >= 2, an even number of owned planes (%d) and %d halo planes per side "
+                  "that fit a neighbour's slab and do not meet around the period (%d planes)", nz, H, Mz);
+        return MSM_AMD_EINVAL;
+    }
+    if (mode == MSM_AMD_SLAB_ALLGATHER) return MSM_AMD_SLAB_ALLGATHER;
+    if (mode != MSM_AMD_SLAB_AUTO) { set_error("slab step: unknown exchange mode %d", mode); return MSM_AMD_EINVAL; }
+    return (can_halo && 2L * H < (long)(world - 1) * nz) ? MSM_AMD_SLAB_HALO : MSM_AMD_SLAB_ALLGATHER;
+}
+
+extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *coll, const double *d_r, const double *d_q,
+                                 double *d_acc, int mode) {
+    if (!h || !d_r || !d_q || !d_acc) { set_error("msm_amd_slab_step: null argument"); return MSM_AMD_EINVAL; }
+    const msm_amd_plan_desc &d = h->hp.d;
+    const int world = coll ? coll->world : 1;
+    const bool slab = d.nzplanes < d.M[2];
+    if (slab && (!coll || world < 2)) { set_error("msm_amd_slab_step: a handle that owns some of the planes needs the collectives"); return MSM_AMD_EINVAL; }
+    if (h->small_box || h->hp.literal || !(h->anterp_tiled && h->opt_anterp_tiled) || h->opt_pair_variant < 5 ||
+        h->pp.convention == MSM_AMD_ACC_LITERAL) {
+        set_error("msm_amd_slab_step: needs the cluster pair sum and the tiled grid transfer (grid of at least 24 nodes per axis, "
+                  "at least 3 cutoffs per cell edge, not the literal mode)");
+        return MSM_AMD_EINVAL;
+    }
+    int xmode = MSM_AMD_SLAB_ALLGATHER;
+    if (slab) {
+        xmode = msm_amd_slab_exchange_mode(h, world, mode);
+        if (xmode < 0) return xmode;
+        if ((long)d.nzplanes * world != d.M[2] || d.zplane0 != coll->rank * d.nzplanes) {
+            set_error("msm_amd_slab_step: rank %d of %d must own planes [%d, %d) of %d", coll->rank, world, coll->rank * (d.M[2] / world),
+                      (coll->rank + 1) * (d.M[2] / world), d.M[2]);
+            return MSM_AMD_EINVAL;
+        }
+    }
+    HIPCHK(hipSetDevice(h->device));
+    int rc;
+    const bool two = h->opt_slab_overlap != 0;
+    if (two && (rc = ensure_stream_b(h))) return rc;
+    if (!h->acc_grid && (rc = dalloc(&h->acc_grid, 3 * (size_t)h->capacity))) return rc;
+    h->pk_recorded = false;
+    hipStream_t a = h->stream, b = two ? h->stream_b : h->stream;
+    const size_t plane = (size_t)d.M[0] * d.M[1];
+    if ((rc = msm_amd_stage_bin(h, d_r, d_q))) return rc;
+    if (two) {
+        HIPCHK(hipEventRecord(h->ev_fork, a));
+        HIPCHK(hipStreamWaitEvent(b, h->ev_fork, 0));
+    }
+    // stream a: neighbour lists and the pair sum, which need nothing from the other ranks
+    const int wgs_before = h->pair_wgs_now;
+    if (two && h->opt_pair_wgs > 0) h->pair_wgs_now = h->opt_pair_wgs;
+    rc = msm_amd_stage_pairs(h, d_acc);
+    h->pair_wgs_now = wgs_before;
+    if (rc) return rc;
+    // stream b: the grid branch
+    h->stream = b; // the stage functions enqueue on the handle's stream
+    rc = 0;
+    do {
+        if ((rc = msm_amd_stage_anterpolate(h))) break;
+        double *q0 = h->gq[0];
+        if (slab && xmode == MSM_AMD_SLAB_ALLGATHER) {
+            if (coll->all_gather(coll->ctx, q0 + plane * d.zplane0, q0, plane * d.nzplanes, (void *)b)) {
+                set_error("slab step: the all-gather of the level-0 charges failed");
+                rc = MSM_AMD_EHIP;
+                break;
+            }
+        } else if (slab) {
+            const int H = slab_halo_planes(h), Mz = d.M[2], z0 = d.zplane0, nz = d.nzplanes;
+            const int up = (coll->rank + 1) % world, down = (coll->rank + world - 1) % world;
+            // z0 - H and z0 + nz are multiples of nothing in particular, but each range stays inside the grid: H <= nz
+            if (coll->halo_exchange(coll->ctx, q0 + plane * (z0 + nz - H), q0 + plane * z0, q0 + plane * ((z0 - H + Mz) % Mz),
+                                    q0 + plane * ((z0 + nz) % Mz), plane * H, up, down, (void *)b)) {
+                set_error("slab step: the halo exchange of the level-0 charges failed");
+                rc = MSM_AMD_EHIP;
+                break;
+            }
+        }
+        if ((rc = grid_stage(h, slab && xmode == MSM_AMD_SLAB_HALO ? coll : nullptr))) break;
+        if (hipMemsetAsync(h->acc_grid, 0, 3 * (size_t)h->N * sizeof(double), b) != hipSuccess) { rc = MSM_AMD_EHIP; break; }
+        if ((rc = msm_amd_stage_interpolate(h, h->acc_grid))) break;
+        if (two && hipEventRecord(h->ev_join, b) != hipSuccess) rc = MSM_AMD_EHIP;
+    } while (0);
+    h->stream = a;
+    if (rc) {
+        if (rc == MSM_AMD_EHIP && !*msm_amd_last_error()) set_error("slab step: a HIP call failed");
+        return rc;
+    }
+    if (two) HIPCHK(hipStreamWaitEvent(a, h->ev_join, 0));
+    // acc = pair part + grid part: the same addition the one-stream evaluation makes inside the interpolation kernel
+    launch_axpy(a, d_acc, h->acc_grid, 3 * (size_t)h->n_owned);
+    if ((rc = queue_energies(h, true))) return rc;
+    if (coll && world > 1 && coll->all_reduce_sum(coll->ctx, h->d_energies, 5, (void *)a)) {
+        set_error("slab step: the all-reduce of the energy sums failed");
+        return MSM_AMD_EHIP;
+    }
+    HIPCHK(hipGetLastError());
+    return MSM_AMD_OK;
+}
+
+extern "C" int msm_amd_slab_energies(msm_amd_handle *h, const msm_amd_collectives *coll, double energies[MSM_AMD_U_COUNT]) {
+    if (!h || !energies) return MSM_AMD_EINVAL;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->h_energies, h->d_energies, 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double sums[5];
+    memcpy(sums, h->h_energies, sizeof(sums));
+    if (coll && coll->world > 1) sums[2] /= coll->world; // the Fourier term is the same on every rank: the all-reduce added it world times
+    return msm_amd_combine_energies(h, sums, energies);
+}
+
+// ---------------------------------------------------------------------------
+// the collectives over RCCL (loaded on first use, so that programs that never split a system need no librccl)
+// ---------------------------------------------------------------------------
+namespace {
+struct RcclId { char internal[128]; };
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(RcclId *) = nullptr;
+    int (*CommInitRank)(void **, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+} g_rccl;
+std::mutex g_rccl_mu;
+const int RCCL_DOUBLE = 8, RCCL_SUM = 0; // ncclFloat64, ncclSum
+
+int rccl_load() {
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    if (g_rccl.lib) return MSM_AMD_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *lib = nullptr;
+    for (const char *n : names)
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) { set_error("librccl.so could not be loaded: %s", dlerror()); return MSM_AMD_ENODEV; }
+    RcclApi api;
+    api.lib = lib;
+#define SYM(field, name)                                                                       \
+    do {                                                                                       \
+        *(void **)(&api.field) = dlsym(lib, name);                                             \
+        if (!api.field) { set_error("librccl.so has no %s", name); dlclose(lib); return MSM_AMD_ENODEV; } \
+    } while (0)
+    SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+    SYM(AllGather, "ncclAllGather"); SYM(AllReduce, "ncclAllReduce"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
+    SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl = api;
+    return MSM_AMD_OK;
+}
+int rccl_check(int r, const char *what) {
+    if (r == 0) return 0;
+    set_error("%s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    return MSM_AMD_EHIP;
+}
+int rccl_all_gather(void *ctx, const double *send, double *recv, size_t count, void *stream) {
+    return rccl_check(g_rccl.AllGather(send, recv, count, RCCL_DOUBLE, ctx, (hipStream_t)stream), "ncclAllGather");
+}
+int rccl_all_reduce_sum(void *ctx, double *buf, size_t count, void *stream) {
+    return rccl_check(g_rccl.AllReduce(buf, buf, count, RCCL_DOUBLE, RCCL_SUM, ctx, (hipStream_t)stream), "ncclAllReduce");
+}
+int rccl_halo_exchange(void *ctx, const double *send_up, const double *send_down, double *recv_from_down, double *recv_from_up,
+                       size_t count, int up, int down, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int rc = rccl_check(g_rccl.GroupStart(), "ncclGroupStart");
+    if (rc) return rc;
+    // every rank posts (send up, receive from below) before (send down, receive from above): with two ranks, where both
+    // neighbours are the same peer, its receives then meet the sends in order
+    int r1 = g_rccl.Send(send_up, count, RCCL_DOUBLE, up, ctx, st);
+    int r2 = g_rccl.Recv(recv_from_down, count, RCCL_DOUBLE, down, ctx, st);
+    int r3 = g_rccl.Send(send_down, count, RCCL_DOUBLE, down, ctx, st);
+    int r4 = g_rccl.Recv(recv_from_up, count, RCCL_DOUBLE, up, ctx, st);
+    int r5 = g_rccl.GroupEnd();
+    return rccl_check(r1 ? r1 : (r2 ? r2 : (r3 ? r3 : (r4 ? r4 : r5))), "ncclSend / ncclRecv (halo exchange)");
+}
+} // namespace
+
+extern "C" int msm_amd_rccl_unique_id(char id[128]) {
+    if (!id) return MSM_AMD_EINVAL;
+    int rc = rccl_load();
+    if (rc) return rc;
+    RcclId u;
+    if ((rc = rccl_check(g_rccl.GetUniqueId(&u), "ncclGetUniqueId"))) return rc;
+    memcpy(id, u.internal, 128);
+    return MSM_AMD_OK;
+}
+extern "C" int msm_amd_rccl_create(const char id[128], int rank, int world, msm_amd_collectives **out) {
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) { set_error("msm_amd_rccl_create: bad argument"); return MSM_AMD_EINVAL; }
+    int rc = rccl_load();
+    if (rc) return rc;
+    RcclId u;
+    memcpy(u.internal, id, 128);
+    void *comm = nullptr;
+    if ((rc = rccl_check(g_rccl.CommInitRank(&comm, world, u, rank), "ncclCommInitRank"))) return rc;
+    msm_amd_collectives *c = new msm_amd_collectives();
+    c->rank = rank; c->world = world; c->ctx = comm;
+    c->all_gather = rccl_all_gather; c->all_reduce_sum = rccl_all_reduce_sum; c->halo_exchange = rccl_halo_exchange;
+    *out = c;
+    return MSM_AMD_OK;
+}
+extern "C" void msm_amd_rccl_destroy(msm_amd_collectives *c) {
+    if (!c) return;
+    if (c->ctx && g_rccl.CommDestroy) g_rccl.CommDestroy(c->ctx);
+    delete c;
 }
 
 extern "C" int msm_amd_write_msmsimple_cache(msm_amd_handle *h, const char *dir) {

@@ -905,6 +905,8 @@ struct Transfer3 {
     int Mf[3], Mc[3]; // fine and coarse grid
     int h;
     double J[4];
+    int z0, nz;       // tiled kernels: output planes [z0, z0 + nz) (coarse planes of a restriction, fine planes of a
+                      // prolongation), taken modulo the grid; a slab rank transfers only the planes it needs
 };
 
 // coarse[m] = sum_jz J sum_jy J sum_jx J fine[2m + j]
@@ -964,6 +966,7 @@ __global__ __launch_bounds__(256) void k_prolong3(const double *__restrict__ coa
 static Transfer3 make_transfer(const int Mf[3], int p, const double J[4]) {
     Transfer3 t;
     for (int d = 0; d < 3; d++) { t.Mf[d] = Mf[d]; t.Mc[d] = Mf[d] / 2; }
+    t.z0 = 0; t.nz = 0;
     t.h = p / 2;
     for (int k = 0; k < 4; k++) t.J[k] = J[k];
     return t;
@@ -997,7 +1000,8 @@ __global__ __launch_bounds__(TR_THREADS) void k_restrict_tiled(const double *__r
     __shared__ double t1[NF][NF][TR_T];      // [z fine][y fine][x coarse]
     __shared__ double t2[NF][TR_T][TR_T];    // [z fine][y coarse][x coarse]
     const int ntx = (t.Mc[0] + TR_T - 1) / TR_T, nty = (t.Mc[1] + TR_T - 1) / TR_T;
-    const int X0 = (blockIdx.x % ntx) * TR_T, Y0 = ((blockIdx.x / ntx) % nty) * TR_T, Z0 = (blockIdx.x / (ntx * nty)) * TR_T;
+    const int X0 = (blockIdx.x % ntx) * TR_T, Y0 = ((blockIdx.x / ntx) % nty) * TR_T;
+    const int ZT = (blockIdx.x / (ntx * nty)) * TR_T, Z0 = t.z0 + ZT; // Z0 may run past the grid: planes are taken modulo
     // x: t1[zi][yi][xc] = sum_j J|j| fine[2 (X0 + xc) + j, 2 Y0 - H + yi, 2 Z0 - H + zi]
     for (int o = threadIdx.x; o < NF * NF * TR_T; o += TR_THREADS) {
         const int xc = o % TR_T, yi = (o / TR_T) % NF, zi = o / (TR_T * NF);
@@ -1021,11 +1025,11 @@ __global__ __launch_bounds__(TR_THREADS) void k_restrict_tiled(const double *__r
     // z: coarse[X0 + xc, Y0 + yc, Z0 + zc] = sum_j J|j| t2[2 zc + j + H][yc][xc]
     for (int o = threadIdx.x; o < TR_T * TR_T * TR_T; o += TR_THREADS) {
         const int xc = o % TR_T, yc = (o / TR_T) % TR_T, zc = o / (TR_T * TR_T);
-        if (X0 + xc >= t.Mc[0] || Y0 + yc >= t.Mc[1] || Z0 + zc >= t.Mc[2]) continue;
+        if (X0 + xc >= t.Mc[0] || Y0 + yc >= t.Mc[1] || ZT + zc >= t.nz) continue;
         double s = 0.0;
 #pragma unroll
         for (int j = -H; j <= H; j++) s = fma(t.J[j < 0 ? -j : j], t2[2 * zc + j + H][yc][xc], s);
-        coarse[((size_t)(Z0 + zc) * t.Mc[1] + (Y0 + yc)) * t.Mc[0] + (X0 + xc)] = s;
+        coarse[((size_t)modp(Z0 + zc, t.Mc[2]) * t.Mc[1] + (Y0 + yc)) * t.Mc[0] + (X0 + xc)] = s;
     }
 }
 
@@ -1040,7 +1044,8 @@ __global__ __launch_bounds__(128) void k_prolong_tiled(const double *__restrict_
     __shared__ double t1[TF][NC][NP]; // [z fine][y coarse][x coarse]
     __shared__ double t2[TF][TF][NP]; // [z fine][y fine][x coarse]
     const int ntx = (t.Mf[0] + TF - 1) / TF, nty = (t.Mf[1] + TF - 1) / TF;
-    const int X0 = (blockIdx.x % ntx) * TF, Y0 = ((blockIdx.x / ntx) % nty) * TF, Z0 = (blockIdx.x / (ntx * nty)) * TF;
+    const int X0 = (blockIdx.x % ntx) * TF, Y0 = ((blockIdx.x / ntx) % nty) * TF;
+    const int ZT = (blockIdx.x / (ntx * nty)) * TF, Z0 = t.z0 + ZT; // may be negative or run past the grid: taken modulo
     const int cx0 = X0 / 2 - 2, cy0 = Y0 / 2 - 2;
     const size_t plane = (size_t)t.Mc[0] * t.Mc[1];
     for (int o = threadIdx.x; o < TF * NC * NC; o += 128) {
@@ -1072,7 +1077,7 @@ __global__ __launch_bounds__(128) void k_prolong_tiled(const double *__restrict_
     __syncthreads();
     for (int o = threadIdx.x; o < TF * TF * TF; o += 128) {
         const int xf = o % TF, yf = (o / TF) % TF, zf = o / (TF * TF);
-        if (X0 + xf >= t.Mf[0] || Y0 + yf >= t.Mf[1] || Z0 + zf >= t.Mf[2]) continue;
+        if (X0 + xf >= t.Mf[0] || Y0 + yf >= t.Mf[1] || ZT + zf >= t.nz) continue;
         const int n = X0 + xf;
         double s = 0.0;
 #pragma unroll
@@ -1081,20 +1086,24 @@ __global__ __launch_bounds__(128) void k_prolong_tiled(const double *__restrict_
             if (u & 1) continue;
             s = fma(t.J[j < 0 ? -j : j], t2[zf][yf][u / 2 - cx0], s);
         }
-        const size_t idx = ((size_t)(Z0 + zf) * t.Mf[1] + (Y0 + yf)) * t.Mf[0] + (X0 + xf);
+        const size_t idx = ((size_t)modp(Z0 + zf, t.Mf[2]) * t.Mf[1] + (Y0 + yf)) * t.Mf[0] + (X0 + xf);
         fine[idx] = fine[idx] + s;
     }
 }
-void launch_prolong_tiled_add(hipStream_t st, const double *coarse, double *fine, const int Mf[3], int p, const double J[4]) {
-    const Transfer3 t = make_transfer(Mf, p, J);
-    const int nb = ((t.Mf[0] + PR_T - 1) / PR_T) * ((t.Mf[1] + PR_T - 1) / PR_T) * ((t.Mf[2] + PR_T - 1) / PR_T);
+void launch_prolong_tiled_add(hipStream_t st, const double *coarse, double *fine, const int Mf[3], int p, const double J[4], int z0,
+                              int nz) {
+    Transfer3 t = make_transfer(Mf, p, J);
+    t.z0 = z0; t.nz = nz; // fine planes [z0, z0 + nz) modulo Mf[2]
+    const int nb = ((t.Mf[0] + PR_T - 1) / PR_T) * ((t.Mf[1] + PR_T - 1) / PR_T) * ((nz + PR_T - 1) / PR_T);
     if (p == 4) hipLaunchKernelGGL((k_prolong_tiled<2>), dim3(nb), dim3(128), 0, st, coarse, fine, t);
     else hipLaunchKernelGGL((k_prolong_tiled<3>), dim3(nb), dim3(128), 0, st, coarse, fine, t);
 }
 
-void launch_restrict_tiled(hipStream_t st, const double *fine, double *coarse, const int Mf[3], int p, const double J[4]) {
-    const Transfer3 t = make_transfer(Mf, p, J);
-    const int nb = ((t.Mc[0] + TR_T - 1) / TR_T) * ((t.Mc[1] + TR_T - 1) / TR_T) * ((t.Mc[2] + TR_T - 1) / TR_T);
+void launch_restrict_tiled(hipStream_t st, const double *fine, double *coarse, const int Mf[3], int p, const double J[4], int z0,
+                           int nz) {
+    Transfer3 t = make_transfer(Mf, p, J);
+    t.z0 = z0; t.nz = nz; // coarse planes [z0, z0 + nz) modulo Mc[2]
+    const int nb = ((t.Mc[0] + TR_T - 1) / TR_T) * ((t.Mc[1] + TR_T - 1) / TR_T) * ((nz + TR_T - 1) / TR_T);
     if (p == 4) hipLaunchKernelGGL((k_restrict_tiled<2>), dim3(nb), dim3(TR_THREADS), 0, st, fine, coarse, t);
     else hipLaunchKernelGGL((k_restrict_tiled<3>), dim3(nb), dim3(TR_THREADS), 0, st, fine, coarse, t);
 }

@@ -107,8 +107,9 @@ void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, i
 // variant 0: build lists, then one wave per cluster walks its list; variant 1: no lists, every wave enumerates and
 // evaluates its candidates directly.  Clusters whose list overflowed list_stride are evaluated by the direct kernel.
 // ev (optional): two events recorded immediately before and after the list-walking kernel
+// max_wgs > 0 caps the workgroups of the list-walking kernel (variant 3), which then loops over its clusters
 void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double *acc,
-                          double *epart, int variant, int n_total, hipEvent_t *ev);
+                          double *epart, int variant, int n_total, hipEvent_t *ev, int max_wgs = 0);
 
 // ---- short range ----
 void launch_pair_cells(hipStream_t st, const double4 *ps, const int *cstart, const int *order, int ncell,
@@ -169,8 +170,11 @@ struct ConvBatch {
     double *e[8];
 };
 // the three axis passes of a restriction in one launch, tile by tile through LDS (same bits as the separate passes)
-void launch_restrict_tiled(hipStream_t st, const double *fine, double *coarse, const int Mf[3], int p, const double J[4]);
-void launch_prolong_tiled_add(hipStream_t st, const double *coarse, double *fine, const int Mf[3], int p, const double J[4]);
+// z0, nz: the output planes [z0, z0 + nz), modulo the grid (coarse planes of the restriction, fine planes of the prolongation)
+void launch_restrict_tiled(hipStream_t st, const double *fine, double *coarse, const int Mf[3], int p, const double J[4], int z0,
+                           int nz);
+void launch_prolong_tiled_add(hipStream_t st, const double *coarse, double *fine, const int Mf[3], int p, const double J[4], int z0,
+                              int nz);
 bool launch_conv_multi(hipStream_t st, ConvBatch &B);
 // coarsest level + Fourier level, both full-period, as offset tables Ta (sum) and Tb (Fourier part): ea = Ta * q, eb = Tb * q
 void launch_conv_small_pair(hipStream_t st, const double *q, const double *Ta, const double *Tb, const int M[3], double *ea,

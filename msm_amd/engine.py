@@ -200,6 +200,22 @@ class Engine:
         check(load().msm_amd_combine_energies(self._h, s.ctypes.data_as(_dp), en.ctypes.data_as(_dp)), "combine_energies")
         return en
 
+    def slab_step(self, coll, r, q, acc, mode=capi.SLAB_AUTO):
+        """msm_amd_slab_step: one evaluation of a slab rank with its exchange steps through `coll` (a pointer to a
+        capi.Collectives, or None for a handle that owns the whole grid); queued, nothing waits for the GPU."""
+        check(load().msm_amd_slab_step(self._h, coll, r.data_ptr(), q.data_ptr(), acc.data_ptr(), int(mode)), "msm_amd_slab_step")
+
+    def slab_energies(self, coll):
+        en = np.zeros(capi.U_COUNT)
+        check(load().msm_amd_slab_energies(self._h, coll, en.ctypes.data_as(_dp)), "msm_amd_slab_energies")
+        return en
+
+    def slab_exchange_mode(self, world, mode=capi.SLAB_AUTO):
+        m = load().msm_amd_slab_exchange_mode(self._h, int(world), int(mode))
+        if m < 0:
+            check(m, "msm_amd_slab_exchange_mode")
+        return m
+
     def _wrap(self, ptr, shape):
         """Zero-copy float64 torch view of device memory owned by the handle."""
         class _Wrap:

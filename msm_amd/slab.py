@@ -18,10 +18,111 @@ The level-0 convolution — the only grid stage with real work — is evaluated 
 plus p/2 planes either side (the interpolation support), so potentials need no halo exchange either.
 """
 import copy
+import ctypes as C
 
 import numpy as np
 
 from . import capi
+
+
+# ---------------------------------------------------------------------------
+# collectives for msm_amd_slab_step (struct msm_amd_collectives)
+# ---------------------------------------------------------------------------
+class RcclCollectives:
+    """The library's own RCCL table (msm_amd_rccl_create): collectives queued on the engine's streams.  The 128-byte
+    unique id travels from rank 0 over the torch.distributed group that is already up."""
+
+    def __init__(self, torch, dist, rank, world, device):
+        lib = capi.load()
+        idbuf = C.create_string_buffer(128)
+        if rank == 0:
+            capi.check(lib.msm_amd_rccl_unique_id(idbuf), "msm_amd_rccl_unique_id")
+        on_dev = dist.get_backend() == "nccl"
+        t = torch.tensor(list(idbuf.raw), dtype=torch.uint8, device=device if on_dev else "cpu")
+        dist.broadcast(t, 0)
+        raw = bytes(t.cpu().tolist())
+        self._p = C.POINTER(capi.Collectives)()
+        with torch.cuda.device(device):
+            capi.check(lib.msm_amd_rccl_create(raw, rank, world, C.byref(self._p)), "msm_amd_rccl_create")
+        self.ptr = self._p
+
+    def close(self):
+        if self._p:
+            capi.load().msm_amd_rccl_destroy(self._p)
+            self._p = C.POINTER(capi.Collectives)()
+
+
+class _PythonCollectives:
+    """A struct msm_amd_collectives whose functions are Python callables (kept alive by this object)."""
+
+    def __init__(self, rank, world, all_gather, all_reduce_sum, halo_exchange):
+        self._fns = (capi.ALL_GATHER_FN(all_gather), capi.ALL_REDUCE_FN(all_reduce_sum), capi.HALO_EXCHANGE_FN(halo_exchange))
+        self._c = capi.Collectives(rank, world, None, *self._fns)
+        self.ptr = C.pointer(self._c)
+
+    def close(self):
+        pass
+
+
+class NullCollectives(_PythonCollectives):
+    """Collectives that move nothing: the work of ONE rank of a `world`-rank run timed on one GPU (tools/rank_sim.py)."""
+
+    def __init__(self, rank, world):
+        super().__init__(rank, world, lambda *a: 0, lambda *a: 0, lambda *a: 0)
+
+
+class HostStagedCollectives(_PythonCollectives):
+    """The table over a torch.distributed group that cannot move device memory (gloo): every call synchronises the
+    device, stages through the host and copies the result back.  For functional tests with several ranks on one GPU."""
+
+    def __init__(self, torch, dist, rank, world, device):
+        def view(ptr, count):
+            class _W:
+                pass
+            w = _W()
+            w.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+            return torch.as_tensor(w, device=device)
+
+        def guarded(fn):
+            def call(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception:        # an exception must not unwind through the C caller
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return call
+
+        def all_gather(ctx, send, recv, count, stream):
+            torch.cuda.synchronize(device)
+            mine = view(send, count).cpu()
+            parts = [torch.empty(count, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            view(recv, count * world).copy_(torch.cat(parts))
+            torch.cuda.synchronize(device)
+
+        def all_reduce_sum(ctx, buf, count, stream):
+            torch.cuda.synchronize(device)
+            t = view(buf, count).cpu()
+            dist.all_reduce(t)
+            view(buf, count).copy_(t)
+            torch.cuda.synchronize(device)
+
+        def halo_exchange(ctx, send_up, send_down, recv_from_down, recv_from_up, count, up, down, stream):
+            torch.cuda.synchronize(device)
+            su, sd = view(send_up, count).cpu(), view(send_down, count).cpu()
+            rd, ru = torch.empty(count, dtype=torch.float64), torch.empty(count, dtype=torch.float64)
+            # tags tell the two messages apart when up == down (two ranks)
+            ops = [dist.P2POp(dist.isend, su, up, tag=1), dist.P2POp(dist.irecv, rd, down, tag=1),
+                   dist.P2POp(dist.isend, sd, down, tag=2), dist.P2POp(dist.irecv, ru, up, tag=2)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            view(recv_from_down, count).copy_(rd)
+            view(recv_from_up, count).copy_(ru)
+            torch.cuda.synchronize(device)
+
+        super().__init__(rank, world, guarded(all_gather), guarded(all_reduce_sum), guarded(halo_exchange))
 
 
 def slab_planes(Mz, world, rank):
@@ -64,7 +165,7 @@ class SlabRank:
     alone."""
 
     def __init__(self, torch, dist, msm_amd, desc, r_all, q_all, rank, world, local_rank=0, margin=2e-4,
-                 engine_factory=None, perturb=False, headroom=1.02):
+                 engine_factory=None, perturb=False, headroom=1.02, mode=capi.SLAB_AUTO, collectives=None, c_step=True):
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
         self.z0, self.nz = slab_planes(desc.M[2], world, rank)
         own, hal = select_slab(r_all, desc.A[2], desc.M[2], world, rank, halo_width(desc, margin if perturb else 0.0))
@@ -93,6 +194,18 @@ class SlabRank:
             self.delta = (torch.rand(self.r.shape, generator=g, dtype=torch.float64, device=dev) - 0.5) * margin
             self.sign = 1.0
         self._pending = self._pending_work = self._energies = None
+        # The real engine runs the whole step in C (msm_amd_slab_step: pair sum beside the grid branch on two streams,
+        # collectives from a table); a stand-in engine (CPU tests of the partition logic) is driven stage by stage below.
+        self.mode = mode
+        self.coll = None
+        if hasattr(self.eng, "slab_step") and world > 1 and c_step:
+            if collectives is not None:
+                self.coll = collectives
+            elif dist.get_backend() == "nccl":
+                self.coll = RcclCollectives(torch, dist, rank, world, dev)
+            else:
+                self.coll = HostStagedCollectives(torch, dist, rank, world, dev)
+                self.eng.set_option("slab_overlap", 0)   # ranks sharing a GPU: one stream per process
 
     def exchange(self):
         """Particle migration and halo refresh after the owned particles have moved (self.r[:n_own] rewritten by the
@@ -184,6 +297,12 @@ class SlabRank:
         if self.perturb:
             self.r.add_(self.delta, alpha=self.sign)
             self.sign = -self.sign
+        if self.coll is not None:
+            mark("step")
+            eng.slab_step(self.coll.ptr, self.r, self.q, self.acc, self.mode)
+            mark("end")
+            self._pending, self._pending_work, self._energies = "c", None, None
+            return self.last_energies if want_energies else None
         mark("bin")
         eng.stage_bin(self.r, self.q)
         mark("anterpolation")
@@ -212,6 +331,8 @@ class SlabRank:
 
     @property
     def last_energies(self):
+        if self._energies is None and isinstance(self._pending, str):
+            self._energies = self.eng.slab_energies(self.coll.ptr)
         if self._energies is None and self._pending is not None:
             if self._pending_work is not None:
                 self._pending_work.wait()

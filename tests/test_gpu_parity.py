@@ -172,16 +172,16 @@ def test_pair_kernel_variants_agree(msm, torch):
     eng = msm.Engine(desc)
     rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
     out = []
-    for v in (1, 2, 3, 4, 5, 6, 7, 8):  # 1-4: cell lists; 5: cluster pairs with lists; 6: list-free; 7: lists, every pair from both sides; 8: lists walked per particle
+    for v in (1, 2, 3, 4, 5, 6, 7, 8, 9):  # 1-4: cell lists; 5: cluster pairs with lists; 6: list-free; 7: lists, every pair from both sides; 8: lists walked per particle; 9: the same with survivors split by the half of the cluster they are near
         eng.set_option("pair_variant", v)
         en, acc = eng.eval(rd, qd)
         out.append((en.copy(), acc.cpu().numpy().copy()))
-    for k in (1, 2, 3, 4, 5, 6, 7):
+    for k in (1, 2, 3, 4, 5, 6, 7, 8):
         assert rel_rms(out[k][1], out[0][1]) < 1e-13
         assert abs(out[k][0][0] - out[0][0][0]) < 1e-13 * abs(out[0][0][0])
     sp = spec_for(desc)
     aw, au, ureal = sp.pairs(r, q)
-    for v in (1, 2, 3, 4, 5, 6, 7, 8):
+    for v in (1, 2, 3, 4, 5, 6, 7, 8, 9):
         eng.set_option("pair_variant", v)
         eng.stage_bin(rd, qd)
         a2 = torch.zeros((N, 3), dtype=torch.float64, device="cuda:0")
@@ -514,7 +514,7 @@ def test_edge_cases(msm, torch):
     eng = msm.Engine(d)
     sp = spec_for(d)
     ref = sp.eval(r, q)
-    for v in (1, 2, 3, 4, 5, 6, 7, 8):   # the crowded region overflows the cluster lists: the list-free kernel takes over
+    for v in (1, 2, 3, 4, 5, 6, 7, 9, 8):   # the crowded region overflows the cluster lists: the list-free kernel takes over
         eng.set_option("pair_variant", v)
         en, acc = eng.eval(r, q)
         assert np.abs(en - ref["energies"]).max() < TOL * np.abs(ref["energies"][:6]).max(), v
@@ -559,7 +559,7 @@ def test_full_size_properties(msm, torch):
         assert np.array_equal(en, en2) and np.array_equal(acc, acc2.cpu().numpy())
     eng.set_option("overlap", 0)
     # the pair kernel variants agree at full size
-    for v in (1, 2, 3, 4, 6, 7, 8, 5):
+    for v in (1, 2, 3, 4, 6, 7, 9, 8, 5):
         eng.set_option("pair_variant", v)
         en3, acc3 = eng.eval(rd, qd)
         assert rel_rms(acc3.cpu().numpy(), acc) < 1e-13, v

@@ -11,7 +11,23 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, N, p, L, out_dir):
+def _plan(msm_amd, spec):
+    """spec = ("auto", N, p, L) for the reference's parameter choices, or ("explicit", N, p, L, M, a): a cubic grid of M
+    nodes per axis and cutoff a, beta and kmax from the reference's own rules (msmPeriodic.c:249-263)."""
+    import math
+    A = (1.0, 1.0, 1.0)
+    if spec[0] == "auto":
+        _, N, p, L = spec
+        return N, msm_amd.plan_auto(N, A, p, 10, 4.0, L)
+    _, N, p, L, M, a = spec
+    lib = msm_amd.load()
+    aL, hL = 2.0 ** L * a, 2.0 ** (L - 1) / M
+    beta = lib.choosebetaNew(1e-12, aL, hL)
+    kmax = int(math.ceil(abs(lib.choosekmax(1e-12, beta, hL))))
+    return N, msm_amd.plan_explicit(N, A, (M, M, M), p, 10, L, a, beta, kmax)
+
+
+def _worker(rank, world, port, spec, mode, c_step, out_dir):
     import faulthandler
     faulthandler.dump_traceback_later(100, exit=True)   # a stuck rank ends with its stacks instead of hanging the run
     import torch
@@ -21,12 +37,14 @@ def _worker(rank, world, port, N, p, L, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, desc = _plan(msm_amd, spec)
     r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=43)
-    desc = msm_amd.plan_auto(N, (1.0, 1.0, 1.0), p, 10, 4.0, L)
-    sr = SlabRank(torch, dist, msm_amd, desc, r, q, rank, world, local_rank=0, perturb=False)
+    sr = SlabRank(torch, dist, msm_amd, desc, r, q, rank, world, local_rank=0, perturb=False, mode=mode, c_step=c_step)
+    used = sr.eng.slab_exchange_mode(world, mode) if c_step else 0
     for _ in range(2):   # twice: the second step must not see state left by the first
         en = sr.step()
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), en=en, idx=sr.own_idx, acc=sr.owned_acc().cpu().numpy())
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), en=en, idx=sr.own_idx, acc=sr.owned_acc().cpu().numpy(), used=used,
+             n_tot=sr.n_tot)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -39,14 +57,28 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,N,p,L", [(2, 40000, 4, 2), (4, 40000, 6, 3)])
-def test_slab_ranks_match_single_gpu(tmp_path, world, N, p, L):
+SLAB_CASES = [
+    # world, plan, exchange mode asked for (0 auto, 1 all-gather, 2 halo), C step, mode expected
+    (2, ("auto", 40000, 4, 2), 0, True, 1),
+    (4, ("auto", 40000, 6, 3), 0, True, 1),                    # 8 planes per rank, 10 halo planes: the all-gather it is
+    (4, ("auto", 40000, 6, 3), 0, False, 0),                   # the stage-by-stage Python step (what a stand-in engine gets)
+    (4, ("explicit", 50000, 4, 3, 64, 0.03), 0, True, 2),      # 16 planes per rank, 5 halo planes: halo exchange
+    (4, ("explicit", 50000, 4, 3, 64, 0.03), 1, True, 1),      # the same plan through the all-gather
+    (2, ("explicit", 50000, 6, 2, 64, 0.03), 2, True, 2),      # two ranks: both neighbours are the same peer
+    # the benchmark's grid split eight ways: 12 planes per rank, cutoff above half a slab (halo particles outnumber the
+    # owned ones), 16 halo planes would not fit the neighbour's slab: all-gather
+    (8, ("explicit", 60000, 6, 4, 96, 0.07), 0, True, 1),
+]
+
+
+@pytest.mark.parametrize("world,spec,mode,c_step,expect", SLAB_CASES)
+def test_slab_ranks_match_single_gpu(tmp_path, world, spec, mode, c_step, expect):
     import torch
     import torch.multiprocessing as mp
     import msm_amd
-    mp.spawn(_worker, args=(world, _free_port(), N, p, L, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), spec, mode, c_step, str(tmp_path)), nprocs=world, join=True)
+    N, desc = _plan(msm_amd, spec)
     r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=43)
-    desc = msm_amd.plan_auto(N, (1.0, 1.0, 1.0), p, 10, 4.0, L)
     eng = msm_amd.Engine(desc)
     en1, acc1 = eng.eval(r, q)
     acc1 = acc1.cpu().numpy()
@@ -57,7 +89,10 @@ def test_slab_ranks_match_single_gpu(tmp_path, world, N, p, L):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % k))
         acc[z["idx"]] = z["acc"]
         seen[z["idx"]] += 1
+        assert int(z["used"]) == expect
         assert np.abs(z["en"] - en1).max() < 1e-12 * scale, (k, z["en"], en1)
+        if world == 8:
+            assert int(z["n_tot"]) > 2 * len(z["idx"])          # more halo copies than owned particles
     assert (seen == 1).all()
     err = np.sqrt(((acc - acc1) ** 2).sum() / (acc1 ** 2).sum())
     assert err < 1e-12, err
@@ -150,3 +185,48 @@ def test_direct_sum_rows_over_ranks(tmp_path):
         assert np.array_equal(z["acc"], acc1[int(z["i0"]):int(z["i1"])])
         rows += int(z["i1"]) - int(z["i0"])
     assert rows == N
+
+
+def test_rccl_collectives_single_rank():
+    """The library's RCCL table (msm_amd_rccl_create) with a communicator of one rank: every entry runs on a stream and
+    leaves the data a one-rank collective must leave (more ranks need more GPUs than this box has)."""
+    import ctypes as C
+    import torch
+    import msm_amd
+    from msm_amd import capi
+    lib = msm_amd.load()
+    idbuf = C.create_string_buffer(128)
+    capi.check(lib.msm_amd_rccl_unique_id(idbuf), "unique_id")
+    p = C.POINTER(capi.Collectives)()
+    torch.cuda.set_device(0)
+    capi.check(lib.msm_amd_rccl_create(idbuf.raw, 0, 1, C.byref(p)), "rccl_create")
+    c = p.contents
+    assert c.rank == 0 and c.world == 1
+    st = torch.cuda.Stream()
+    x = torch.arange(1000, dtype=torch.float64, device="cuda:0") + 0.5
+    y = torch.zeros(1000, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    assert c.all_gather(c.ctx, x.data_ptr(), y.data_ptr(), 1000, st.cuda_stream) == 0
+    assert c.all_reduce_sum(c.ctx, x.data_ptr(), 1000, st.cuda_stream) == 0
+    up, down = torch.zeros(64, dtype=torch.float64, device="cuda:0"), torch.zeros(64, dtype=torch.float64, device="cuda:0")
+    # alone in the ring a rank is its own neighbour: what it sends up it receives from below
+    assert c.halo_exchange(c.ctx, x[:64].data_ptr(), x[100:164].data_ptr(), down.data_ptr(), up.data_ptr(), 64, 0, 0, st.cuda_stream) == 0
+    st.synchronize()
+    ref = torch.arange(1000, dtype=torch.float64) + 0.5
+    assert torch.equal(y.cpu(), ref) and torch.equal(x.cpu(), ref)
+    assert torch.equal(down.cpu(), ref[:64]) and torch.equal(up.cpu(), ref[100:164])
+    # and a whole step through it: a handle that owns every plane
+    N = 20000
+    r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=5)
+    desc = msm_amd.plan_auto(N, (1.0, 1.0, 1.0), 6, 10, 4.0, 2)
+    eng = msm_amd.Engine(desc)
+    rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
+    en1, acc1 = eng.eval(rd, qd)
+    acc1 = acc1.clone()
+    acc2 = torch.zeros_like(acc1)
+    eng.slab_step(p, rd, qd, acc2)
+    en2 = eng.slab_energies(p)
+    assert np.abs(en2 - en1).max() <= 1e-12 * np.abs(en1[:6]).max()
+    assert torch.equal(acc1, acc2)          # pair part + grid part: the same two numbers added either way
+    eng.close()
+    lib.msm_amd_rccl_destroy(p)
