@@ -3,6 +3,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -63,7 +64,6 @@ struct msm_amd_handle {
     const double *cur_r = nullptr, *cur_q = nullptr;
     // host staging for eval_host
     double *s_r = nullptr, *s_q = nullptr, *s_acc = nullptr, *s_acc2 = nullptr;
-    double *acc_grid = nullptr; // slab step: the grid part of the accelerations, added to the pair part at the end
     // profiling
     bool profiling = false;
     hipEvent_t ev[T_COUNT + 1];
@@ -92,9 +92,12 @@ struct msm_amd_handle {
     int opt_grid_streams = 0; // measured: slower (1.68 vs 1.65 ms at 1M; the chain of small kernels does not get CUs while the
                               // level-0 convolution runs), and cross-stream waits stalled with 4 processes sharing one GPU
     hipEvent_t ev_fork = nullptr, ev_pairs = nullptr, ev_join = nullptr;
-    int opt_pair_wgs = 512;   // slab step with two streams: workgroups of the pair kernel (2 per CU), so that the grid branch finds room
-    int pair_wgs_now = 0;     // cap in force for the next pair launch (0: one workgroup per four clusters)
-    int opt_slab_overlap = 1; // slab step: the grid branch on a second stream beside the pair sum (0: one stream, for several
+    double *conv_part = nullptr; // partial sums of a level-0 convolution whose taps are shared out over workgroups (4 grids)
+    int opt_conv_split = 0;      // 0: never (default: measured slower, 128 against 108 us for 18 planes of 96 x 96 in three shares);
+                                 // 1: when a slab rank has few tiles; n > 1: that many shares
+    int pair_wgs_now = 0;     // A/B: cap on the workgroups of the pair kernel (0: one workgroup per four clusters; measured
+                              // slower at 2, 3 and 4 workgroups per CU, and kernels of a second stream gain nothing from the room)
+    int opt_slab_overlap = 1; // slab step: the charge exchange on a second stream beside the pair sum (0: one stream, for several
                               // processes sharing one GPU, where cross-stream waits were seen to stall)
     int opt_overlap = 0; // measured: +5 % evaluations/s, but the pair kernel's workgroups starve the large convolution blocks
     int opt_transfer_fused = 4;              // 4: restriction and prolongation tiled through LDS, one launch per level (default); 3: restriction
@@ -464,7 +467,7 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     hipFree(h->efour); hipFree(h->dKL); hipFree(h->dTsum); hipFree(h->dTfour); hipFree(h->tmpA); hipFree(h->tmpB); hipFree(h->epart); hipFree(h->parts);
     hipFree(h->d_energies);
     if (h->h_energies) hipHostFree(h->h_energies);
-    hipFree(h->s_r); hipFree(h->s_q); hipFree(h->s_acc); hipFree(h->s_acc2); hipFree(h->acc_grid);
+    hipFree(h->s_r); hipFree(h->s_q); hipFree(h->s_acc); hipFree(h->s_acc2); hipFree(h->conv_part);
     if (h->stream_g) {
         hipStreamSynchronize(h->stream_g);
         hipEventDestroy(h->ev_gfork); hipEventDestroy(h->ev_gjoin);
@@ -517,8 +520,8 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "anterp_cols")) { h->sopt.anterp_cols = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "overlap")) { h->opt_overlap = value; return MSM_AMD_OK; }
     if (!strcmp(key, "slab_overlap")) { h->opt_slab_overlap = value; return MSM_AMD_OK; }
-    if (!strcmp(key, "pair_wgs")) { h->opt_pair_wgs = value; return MSM_AMD_OK; }
-    if (!strcmp(key, "pair_wgs_now")) { h->pair_wgs_now = value; return MSM_AMD_OK; } // A/B: also outside the slab step
+    if (!strcmp(key, "conv_split")) { h->opt_conv_split = value; return MSM_AMD_OK; }
+    if (!strcmp(key, "pair_wgs")) { h->pair_wgs_now = value; return MSM_AMD_OK; } // A/B: cap on the pair kernel's workgroups
     if (!strcmp(key, "top_fused")) { h->opt_top_fused = value; return MSM_AMD_OK; }
     if (!strcmp(key, "grid_streams")) { h->opt_grid_streams = value; return MSM_AMD_OK; }
     if (!strcmp(key, "transfer_fused")) { h->opt_transfer_fused = value; return MSM_AMD_OK; }
@@ -694,6 +697,33 @@ static void convolve_ranges(msm_amd_handle *h, const std::vector<PlaneRange> &ra
         ConvBatch B;
         B.n = 0;
         std::vector<size_t> members;
+        // A slab rank convolves a few planes of level 0: fewer tiles (16 x 8 x 16 outputs each) than the chip has CUs,
+        // so the kernel lasts as long as one workgroup needs for all taps of its tile.  The taps are then shared out
+        // over `split` workgroups per tile (by rows sy of the stencil), which leave partial sums that are added
+        // in a fixed order afterwards.
+        int split = 1;
+        {
+            long tiles0 = 0, entries = 0;
+            bool splittable = true;
+            for (const PlaneRange &r : ranges) {
+                const int *M = h->hp.Ml[r.l];
+                if (!(M[0] >= 16 && M[1] >= 8 && M[2] >= 8)) continue;
+                entries++;
+                if (r.l == 0) {
+                    tiles0 += (long)((M[0] + 15) / 16) * ((M[1] + 7) / 8) * ((r.nz + 15) / 16);
+                    if (h->sub_n[0]) splittable = false;
+                }
+            }
+            const long n0 = std::count_if(ranges.begin(), ranges.end(), [](const PlaneRange &r) { return r.l == 0; });
+            if (h->opt_conv_split && splittable && tiles0 > 0 && tiles0 < 200 && h->hp.d.nzplanes < h->hp.d.M[2]) {
+                split = h->opt_conv_split > 1 ? h->opt_conv_split : (tiles0 < 100 ? 5 : 3);
+                while (split > 1 && entries + n0 * (split - 1) > 8) split--;
+            }
+        }
+        const size_t n0grid = (size_t)h->hp.d.M[0] * h->hp.d.M[1] * h->hp.d.M[2];
+        if (split > 1 && !h->conv_part) {
+            if (dalloc(&h->conv_part, 4 * n0grid)) { split = 1; (void)hipGetLastError(); }
+        }
         for (size_t i = 0; i < ranges.size() && B.n < 8; i++) {
             const PlaneRange &r = ranges[i];
             const LevelStencil &S = h->hp.K[r.l];
@@ -701,16 +731,34 @@ static void convolve_ranges(msm_amd_handle *h, const std::vector<PlaneRange> &ra
             if (!(M[0] >= 16 && M[1] >= 8 && M[2] >= 8)) continue; // a short plane range of a large grid is fine
             const int width = h->sub_n[r.l] ? h->sub_s[r.l] : S.size[2]; // taps per axis the kernel is instantiated for
             if (B.n > 0 && width != B.c[0].ks[2]) continue;
-            ConvArgs &c = B.c[B.n];
-            for (int k = 0; k < 3; k++) { c.M[k] = M[k]; c.ks[k] = h->sub_n[r.l] ? width : S.size[k]; c.kf[k] = S.first[k]; }
-            c.z0 = r.z0; c.nz = r.nz; c.accumulate = 0;
-            c.nsub = h->sub_n[r.l] ? h->sub_n[r.l] : 1;
-            B.q[B.n] = h->gq[r.l]; B.Kt[B.n] = h->sub_n[r.l] ? h->dKsub[r.l] : h->dKt[r.l]; B.e[B.n] = h->ge[r.l];
-            B.n++;
+            const int parts = (r.l == 0 && split > 1) ? split : 1;
+            if (B.n + parts > 8) continue;
+            for (int part = 0; part < parts; part++) {
+                ConvArgs &c = B.c[B.n];
+                for (int k = 0; k < 3; k++) { c.M[k] = M[k]; c.ks[k] = h->sub_n[r.l] ? width : S.size[k]; c.kf[k] = S.first[k]; }
+                c.z0 = r.z0; c.nz = r.nz; c.accumulate = 0;
+                c.nsub = h->sub_n[r.l] ? h->sub_n[r.l] : 1;
+                c.sy0 = 0; c.sy1 = 0;
+                if (parts > 1) { c.sy0 = width * part / parts; c.sy1 = width * (part + 1) / parts; }
+                B.q[B.n] = h->gq[r.l]; B.Kt[B.n] = h->sub_n[r.l] ? h->dKsub[r.l] : h->dKt[r.l];
+                B.e[B.n] = part == 0 ? h->ge[r.l] : h->conv_part + (size_t)(part - 1) * n0grid;
+                B.n++;
+            }
             members.push_back(i);
         }
-        if (B.n > 0 && launch_conv_multi(st, B))
-            for (size_t i : members) done[i] = true;
+        if (B.n > 0 && launch_conv_multi(st, B)) {
+            for (size_t i : members) {
+                done[i] = true;
+                const PlaneRange &r = ranges[i];
+                if (r.l == 0 && split > 1) {
+                    // e = ((part 0 + part 1) + part 2) + ..., two partial grids per pass
+                    const size_t plane = (size_t)h->hp.d.M[0] * h->hp.d.M[1], off = plane * r.z0, n = plane * r.nz;
+                    for (int part = 1; part < split; part += 2)
+                        launch_add_parts(st, h->ge[0] + off, h->conv_part + (size_t)(part - 1) * n0grid + off,
+                                         part + 1 < split ? h->conv_part + (size_t)part * n0grid + off : nullptr, n);
+                }
+            }
+        }
     }
     for (size_t i = 0; i < ranges.size(); i++)
         if (!done[i]) convolve_level(h, ranges[i].l, h->gq[ranges[i].l], h->ge[ranges[i].l], ranges[i].z0, ranges[i].nz);
@@ -743,22 +791,34 @@ static void top_level(msm_amd_handle *h) {
     }
 }
 
-// The grid stage.  halo_coll != NULL: a slab rank in halo mode - level 0 holds the owned charge planes and the halo
-// planes received from the z neighbours only, so the first restriction produces the coarse planes under the owned
-// ones and the level-1 charge grid is completed by an all-gather (queued on the handle's stream) before the chain
-// goes on; the coarser levels are then solved by every rank, being too small to shard.
-static int grid_stage(msm_amd_handle *h, const msm_amd_collectives *halo_coll) {
+// The grid stage.  front_done: a slab rank in halo mode - level 0 holds the owned charge planes and the halo planes
+// received from the z neighbours only, and grid_front() has already produced the level-1 charges; the coarser levels
+// are solved by every rank, being too small to shard.
+// First part of the grid stage of a slab rank in halo mode, queued on the handle's current stream: coarse planes under
+// the owned ones from the owned + halo planes of level 0, then the all-gather that completes the level-1 charge grid.
+static int grid_front(msm_amd_handle *h, const msm_amd_collectives *coll) {
+    const msm_amd_plan_desc &d = h->hp.d;
+    const size_t plane1 = (size_t)h->hp.Ml[1][0] * h->hp.Ml[1][1];
+    restrict_level(h, 0, h->gq[0], h->gq[1], d.zplane0 / 2, d.nzplanes / 2);
+    if (coll->all_gather(coll->ctx, h->gq[1] + plane1 * (d.zplane0 / 2), h->gq[1], plane1 * (d.nzplanes / 2), (void *)h->stream)) {
+        set_error("slab step: the all-gather of the level-1 charges failed");
+        return MSM_AMD_EHIP;
+    }
+    return MSM_AMD_OK;
+}
+
+static int grid_stage(msm_amd_handle *h, bool front_done) {
     const msm_amd_plan_desc &d = h->hp.d;
     const int L = d.L, p = d.p;
     hipStream_t st = h->stream;
     const bool slab = d.nzplanes < d.M[2];
     // plane ranges to convolve on level 0: everything, except on a slab rank, where the potentials are needed on the
-    // owned planes plus p/2 planes either side (interpolation support) and the other planes of ge[0] are left at zero
+    // owned planes plus p/2 planes either side (interpolation support) and the other planes of ge[0] are not computed
     std::vector<PlaneRange> fine, coarse;
     if (d.nzplanes < d.M[2]) {
         const int hz = p / 2, Mz = d.M[2];
         int lo = d.zplane0 - hz, n = d.nzplanes + 2 * hz;
-        hipMemsetAsync(h->ge[0], 0, sizeof(double) * (size_t)d.M[0] * d.M[1] * Mz, st);
+        // (the planes of ge[0] outside that range keep whatever they held: nothing reads them)
         if (n >= Mz) fine.push_back({0, 0, Mz});
         else {
             lo = ((lo % Mz) + Mz) % Mz;
@@ -793,17 +853,7 @@ static int grid_stage(msm_amd_handle *h, const msm_amd_collectives *halo_coll) {
         HIPCHK(hipStreamWaitEvent(h->stream_g, h->ev_gfork, 0));
         h->stream = h->stream_g; // the helpers below enqueue on the handle's stream
     }
-    for (int l = 0; l + 1 < L; l++) {
-        if (l == 0 && halo_coll) {
-            const size_t plane1 = (size_t)h->hp.Ml[1][0] * h->hp.Ml[1][1];
-            restrict_level(h, 0, h->gq[0], h->gq[1], d.zplane0 / 2, d.nzplanes / 2);
-            const int rc = halo_coll->all_gather(halo_coll->ctx, h->gq[1] + plane1 * (d.zplane0 / 2), h->gq[1],
-                                                 plane1 * (d.nzplanes / 2), (void *)h->stream);
-            if (rc) { set_error("slab step: the all-gather of the level-1 charges failed (%d)", rc); return MSM_AMD_EHIP; }
-            continue;
-        }
-        restrict_level(h, l, h->gq[l], h->gq[l + 1]);
-    }
+    for (int l = front_done ? 1 : 0; l + 1 < L; l++) restrict_level(h, l, h->gq[l], h->gq[l + 1]);
     if (!two) {
         mark(h, T_CONV);
         std::vector<PlaneRange> all(fine);
@@ -837,7 +887,7 @@ static int grid_stage(msm_amd_handle *h, const msm_amd_collectives *halo_coll) {
 
 extern "C" int msm_amd_stage_grid(msm_amd_handle *h) {
     if (!h) return MSM_AMD_EINVAL;
-    return grid_stage(h, nullptr);
+    return grid_stage(h, false);
 }
 
 extern "C" int msm_amd_stage_interpolate(msm_amd_handle *h, double *d_acc) {
@@ -1097,59 +1147,49 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
     }
     HIPCHK(hipSetDevice(h->device));
     int rc;
-    const bool two = h->opt_slab_overlap != 0;
+    // Two streams: the exchange of the grid charges (and, in halo mode, the first restriction and the all-gather of
+    // the level-1 charges) travels on the second one while the first computes the pair sum, which needs nothing from
+    // the other ranks.  Kernels gain nothing from running side by side here (the pair kernel fills the chip), a
+    // collective in flight does.
+    const bool two = h->opt_slab_overlap != 0 && slab;
     if (two && (rc = ensure_stream_b(h))) return rc;
-    if (!h->acc_grid && (rc = dalloc(&h->acc_grid, 3 * (size_t)h->capacity))) return rc;
     h->pk_recorded = false;
     hipStream_t a = h->stream, b = two ? h->stream_b : h->stream;
     const size_t plane = (size_t)d.M[0] * d.M[1];
     if ((rc = msm_amd_stage_bin(h, d_r, d_q))) return rc;
+    if ((rc = msm_amd_stage_anterpolate(h))) return rc;
     if (two) {
         HIPCHK(hipEventRecord(h->ev_fork, a));
         HIPCHK(hipStreamWaitEvent(b, h->ev_fork, 0));
     }
-    // stream a: neighbour lists and the pair sum, which need nothing from the other ranks
-    const int wgs_before = h->pair_wgs_now;
-    if (two && h->opt_pair_wgs > 0) h->pair_wgs_now = h->opt_pair_wgs;
-    rc = msm_amd_stage_pairs(h, d_acc);
-    h->pair_wgs_now = wgs_before;
-    if (rc) return rc;
-    // stream b: the grid branch
-    h->stream = b; // the stage functions enqueue on the handle's stream
-    rc = 0;
-    do {
-        if ((rc = msm_amd_stage_anterpolate(h))) break;
+    if (slab) {
+        h->stream = b; // the helpers enqueue on the handle's stream
         double *q0 = h->gq[0];
-        if (slab && xmode == MSM_AMD_SLAB_ALLGATHER) {
+        rc = 0;
+        if (xmode == MSM_AMD_SLAB_ALLGATHER) {
             if (coll->all_gather(coll->ctx, q0 + plane * d.zplane0, q0, plane * d.nzplanes, (void *)b)) {
                 set_error("slab step: the all-gather of the level-0 charges failed");
                 rc = MSM_AMD_EHIP;
-                break;
             }
-        } else if (slab) {
+        } else {
             const int H = slab_halo_planes(h), Mz = d.M[2], z0 = d.zplane0, nz = d.nzplanes;
             const int up = (coll->rank + 1) % world, down = (coll->rank + world - 1) % world;
-            // z0 - H and z0 + nz are multiples of nothing in particular, but each range stays inside the grid: H <= nz
+            // every range is contiguous: H <= nz, and z0 is a multiple of nz
             if (coll->halo_exchange(coll->ctx, q0 + plane * (z0 + nz - H), q0 + plane * z0, q0 + plane * ((z0 - H + Mz) % Mz),
                                     q0 + plane * ((z0 + nz) % Mz), plane * H, up, down, (void *)b)) {
                 set_error("slab step: the halo exchange of the level-0 charges failed");
                 rc = MSM_AMD_EHIP;
-                break;
             }
+            if (!rc) rc = grid_front(h, coll);
         }
-        if ((rc = grid_stage(h, slab && xmode == MSM_AMD_SLAB_HALO ? coll : nullptr))) break;
-        if (hipMemsetAsync(h->acc_grid, 0, 3 * (size_t)h->N * sizeof(double), b) != hipSuccess) { rc = MSM_AMD_EHIP; break; }
-        if ((rc = msm_amd_stage_interpolate(h, h->acc_grid))) break;
-        if (two && hipEventRecord(h->ev_join, b) != hipSuccess) rc = MSM_AMD_EHIP;
-    } while (0);
-    h->stream = a;
-    if (rc) {
-        if (rc == MSM_AMD_EHIP && !*msm_amd_last_error()) set_error("slab step: a HIP call failed");
-        return rc;
+        if (!rc && two && hipEventRecord(h->ev_join, b) != hipSuccess) { set_error("slab step: hipEventRecord failed"); rc = MSM_AMD_EHIP; }
+        h->stream = a;
+        if (rc) return rc;
     }
+    if ((rc = msm_amd_stage_pairs(h, d_acc))) return rc;
     if (two) HIPCHK(hipStreamWaitEvent(a, h->ev_join, 0));
-    // acc = pair part + grid part: the same addition the one-stream evaluation makes inside the interpolation kernel
-    launch_axpy(a, d_acc, h->acc_grid, 3 * (size_t)h->n_owned);
+    if ((rc = grid_stage(h, slab && xmode == MSM_AMD_SLAB_HALO))) return rc;
+    if ((rc = msm_amd_stage_interpolate(h, d_acc))) return rc;
     if ((rc = queue_energies(h, true))) return rc;
     if (coll && world > 1 && coll->all_reduce_sum(coll->ctx, h->d_energies, 5, (void *)a)) {
         set_error("slab step: the all-reduce of the energy sums failed");

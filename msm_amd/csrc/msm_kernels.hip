@@ -1430,11 +1430,12 @@ __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
     const int ox = X0 - (c.kf[0] + ca * SZ + SZ - 1), oy = Y0 - (c.kf[1] + cb * SZ + SZ - 1), oz = Z0 - (c.kf[2] + cc * SZ + SZ - 1);
     const double *__restrict__ Kt = B.Kt[lev] + (size_t)cube * (SZ * SZ * SZ);
     const int gx0 = modp(ox + hl, Mx), gx1 = modp(ox + hl + 32, Mx);
-    for (int c0 = 0; c0 < SZ; c0 += CHR) {
-        const int nch = min(CHR, SZ - c0); // this pass applies the taps sy in [c0, c0 + nch)
+    const int sy_lo = c.sy0, sy_hi = c.sy1 > 0 ? c.sy1 : SZ; // the share of the taps this launch entry applies
+    for (int c0 = sy_lo; c0 < sy_hi; c0 += CHR) {
+        const int nch = min(CHR, sy_hi - c0); // this pass applies the taps sy in [c0, c0 + nch)
         const int ys = SZ - c0 - nch;      // first y row (of the full halo) they touch
         const int rows = TY + nch - 1;
-        if (c0 > 0 || cube > 0) __syncthreads();
+        if (c0 > sy_lo || cube > 0) __syncthreads();
         {
             // staging: half a wave per (z, y) row of the tile, lanes along x; the periodic wrap is done once per
             // row (no integer division per element), and the loads of 8 rows are issued before the first store
@@ -1612,6 +1613,17 @@ void launch_conv_literal(hipStream_t st, const double *q, const double *K, const
 __global__ void k_axpy(double *__restrict__ y, const double *__restrict__ x, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] += x[i];
+}
+__global__ void k_add_parts(double *__restrict__ y, const double *__restrict__ a, const double *__restrict__ b, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v = y[i] + a[i];
+    if (b) v += b[i];
+    y[i] = v;
+}
+void launch_add_parts(hipStream_t st, double *y, const double *a, const double *b, size_t n) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_add_parts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, a, b, n);
 }
 void launch_axpy(hipStream_t st, double *y, const double *x, size_t n) {
     hipLaunchKernelGGL(k_axpy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, x, n);

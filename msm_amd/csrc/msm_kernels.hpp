@@ -158,6 +158,9 @@ struct ConvArgs {
     // k_conv_multi only: the stencil is nsub^3 cubes of ks^3 taps, cube (a, b, c) starting at offset kf + ks (a, b, c),
     // stored one after the other (a fastest), each transposed [sy][sx][sz]
     int nsub = 1;
+    // k_conv_multi only: apply the taps sy in [sy0, sy1) (sy1 = 0: all of them).  A thin slab gives the chip fewer tiles
+    // than it has CUs; the taps of a tile are then shared out over several workgroups that write partial sums
+    int sy0 = 0, sy1 = 0;
 };
 // up to 8 convolutions (levels, or plane ranges of a level) that share one launch
 struct ConvBatch {
@@ -197,6 +200,8 @@ bool launch_conv_tiled(hipStream_t st, const double *q, const double *K, const i
 void launch_conv_literal(hipStream_t st, const double *q, const double *K, const int M[3], const int ksize[3],
                          const int kfirst[3], double *e);
 void launch_axpy(hipStream_t st, double *y, const double *x, size_t n);
+// y[i] = (y[i] + a[i]) + b[i] (b may be null), the order fixed
+void launch_add_parts(hipStream_t st, double *y, const double *a, const double *b, size_t n);
 // ---- reductions ----
 // partial sums of a.b in a fixed order -> parts[0..nparts)
 void launch_dot_partials(hipStream_t st, const double *a, const double *b, size_t n, double *parts, int nparts);

@@ -529,17 +529,29 @@ def test_edge_cases(msm, torch):
         msm.Engine(bad)
 
 
-def test_full_size_properties(msm, torch):
-    """N = 1M, L = 4 (the benchmark configuration): properties that hold at any size."""
+@pytest.mark.parametrize("p", [6, 4])
+def test_full_size_properties(msm, torch, p):
+    """N = 1M, L = 4 (the benchmark configuration, p = 6, and its cubic variant): the whole evaluation against the CPU
+    oracle, and properties that hold at any size."""
     N, A = 1000000, (1.0, 1.0, 1.0)
     r, q = O.neutral_system(N, A, seed=20261111 + 1)
-    desc = msm.plan_auto(N, A, 4, 10, 4.0, 0)
+    desc = msm.plan_auto(N, A, p, 10, 4.0, 0)
     assert list(desc.M) == [96, 96, 96] and desc.L == 4
     eng = msm.Engine(desc)
     rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
     en, acc = eng.eval(rd, qd)
     acc = acc.cpu().numpy()
     assert np.isfinite(en).all() and np.isfinite(acc).all()
+    # the oracle on the same million particles (a few seconds on the box's cores): every energy component to 1e-12 of
+    # the largest one - the total is what cancellation leaves of components sixty times larger, so relative to itself it
+    # is held to 1e-10 - and the accelerations to 1e-12 relative RMS
+    ref = spec_for(desc, nthreads=16).eval(r, q)
+    scale = np.abs(ref["energies"][:6]).max()
+    assert np.abs(en - ref["energies"]).max() <= TOL * scale, (en, ref["energies"])
+    assert abs(en[6] - ref["energies"][6]) <= 1e-10 * abs(ref["energies"][6])
+    assert rel_rms(acc, ref["acc"]) < TOL
+    sub = np.random.default_rng(3).choice(N, 2000, replace=False)       # and no single particle is off either
+    assert np.abs(acc[sub] - ref["acc"][sub]).max() <= 1e-11 * np.abs(ref["acc"]).max()
     # charge conservation through anterpolation and every restriction
     for l in range(desc.L):
         assert abs(eng.grid(msm.capi.GRID_Q, l).sum() - q.sum()) < 1e-8
@@ -574,6 +586,66 @@ def test_full_size_properties(msm, torch):
     assert rel_rms(acc5.cpu().numpy(), acc3.cpu().numpy()[perm]) < 1e-10
     # sampled check of the accelerations against the Ewald sum on a subset (accuracy of the method itself)
     eng.close()
+
+
+@pytest.mark.parametrize("p,M", [(4, 32), (6, 32), (4, 48), (6, 48)])
+def test_two_scale_identities(msm, torch, p, M):
+    """The level transfers pinned by the B-spline two-scale relation Phi_2h(x) = sum_j J_j Phi_h(x - j h)
+    (msmLibrary.h:152-153), which no reference run exercises (chooseL is 1 there):
+      restriction of the charges anterpolated on the grid M  ==  the charges anterpolated on the grid M/2,
+      interpolation on M of a prolongated potential  ==  interpolation on M/2 of the potential itself
+    (values and gradients), both to rounding and with no oracle in between.  The coarse grid of M = 32 takes the
+    small-grid spline kernels, every other grid the tiled ones."""
+    N, A = 20000, (1.0, 1.1, 0.9)
+    rng = np.random.default_rng(11)
+    r = rng.random((N, 3)) * np.array(A)
+    q = rng.standard_normal(N)
+    a = 0.12
+    fine = msm.Engine(msm.plan_explicit(N, A, (M, M, M), p, 4, 2, a, 8.0, 4))
+    coarse = msm.Engine(msm.plan_explicit(N, A, (M // 2,) * 3, p, 4, 1, a, 8.0, 4))
+    rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
+    fine.stage_bin(rd, qd)
+    fine.stage_anterpolate()
+    coarse.stage_bin(rd, qd)
+    coarse.stage_anterpolate()
+    qf = torch.as_tensor(fine.grid(msm.capi.GRID_Q, 0), device="cuda:0")
+    qc = torch.zeros((M // 2,) * 3, dtype=torch.float64, device="cuda:0")
+    fine.op_restrict(0, qf, qc)
+    ref = coarse.grid(msm.capi.GRID_Q, 0)
+    assert np.abs(qc.cpu().numpy() - ref).max() < 1e-13 * np.abs(ref).max()
+    ec = rng.standard_normal((M // 2,) * 3)
+    ef = torch.zeros((M, M, M), dtype=torch.float64, device="cuda:0")
+    fine.op_prolong_add(0, torch.as_tensor(ec, device="cuda:0"), ef)
+    fine.set_grid(msm.capi.GRID_E, 0, ef.cpu().numpy())
+    coarse.set_grid(msm.capi.GRID_E, 0, ec)
+    af = torch.zeros((N, 3), dtype=torch.float64, device="cuda:0")
+    ac = torch.zeros_like(af)
+    fine.stage_interpolate(af)
+    coarse.stage_interpolate(ac)
+    assert rel_rms(af.cpu().numpy(), ac.cpu().numpy()) < 1e-13
+    fine.close()
+    coarse.close()
+
+
+def test_accuracy_sweep_point(msm, torch):
+    """One point of the cutoff x order x spacing sweep (abar = 5, quintic spline, the reference's grid choice at 100k
+    particles: 48^3, three levels) against the converged Ewald sum of the same system on the GPU: force error and
+    energy error at the level the sweep tables report for this point (3.5e-5, 2.1e-4), and better than abar = 4."""
+    N, A = 100000, (1.0, 1.0, 1.0)
+    r, q = O.neutral_system(N, A, seed=20261111 + 4)
+    rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
+    u5, _, grad = msm.ewald(rd, qd, A, 22.4, 0.25, 40)
+    grad = grad.cpu().numpy()
+    err = {}
+    for abar in (4.0, 5.0):
+        desc = msm.plan_auto(N, A, 6, 10, abar, 3)
+        assert list(desc.M) == [48, 48, 48]
+        eng = msm.Engine(desc)
+        en, acc = eng.eval(rd, qd)
+        err[abar] = (rel_rms(acc.cpu().numpy(), grad), abs(en[6] - u5[4]) / abs(u5[4]))
+        eng.close()
+    assert err[5.0][0] < 6e-5 and err[5.0][1] < 1e-3, err
+    assert err[5.0][0] < 0.5 * err[4.0][0], err
 
 
 def test_accuracy_vs_ewald_100k(msm, torch):
