@@ -21,7 +21,8 @@ sum): algorithmic flops (ordered in-cutoff pairs x 34 flop at p=4 / 42 at p=6) o
 duration, measured with a pair of HIP events recorded around it on the stream it runs on.  `traffic` is the
 HBM-side byte count of one launch from rocprofv3 PMC passes (profiles/r01_pair_traffic.json; null if that
 file is absent).  `cpu_baseline` is the CPU oracle (a port of the same mathematics, oracle/msm_spec.c) timed on
-this box's host cores on one evaluation of the same system; `parity` compares the GPU result with it.
+this box's host cores on one evaluation of the same system (`reference_literal` inside it: the reference's own
+algorithm on one core at the sizes it can run); `parity` compares the GPU result with it.
 """
 import argparse
 import json
@@ -41,9 +42,20 @@ FP64_PEAK_TFLOPS = 78.6   # gfx950 vector FP64: 256 CU x 128 flop/clk x 2.4 GHz
 FLOP_PER_PAIR = {4: 34, 6: 42}
 
 
+def splitmix64(seed, n):
+    """The first n outputs of SplitMix64 seeded with `seed` (Steele, Lea, Flood 2014): state += 0x9E3779B97F4A7C15, then
+    two xor-shift-multiply rounds; the i-th state is seed + (i + 1) * gamma, so the stream vectorises."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
 def make_system(N, seed):
-    rng = np.random.Generator(np.random.PCG64(seed))
-    r = rng.random((N, 3))
+    """N particles uniform in the unit cube (53-bit fractions of a SplitMix64 stream), charges +1 / -1 alternating:
+    exactly neutral."""
+    r = ((splitmix64(seed, 3 * N) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)).reshape(N, 3)
     q = np.where(np.arange(N) % 2 == 0, 1.0, -1.0)
     return r, q
 
@@ -103,6 +115,12 @@ def main():
             eng.set_option("pair_variant", args.pair_variant)
         stepper.profile = SlabProfiler(torch, stepper).profile
 
+    exchange = ""
+    if world > 1:
+        m = eng.slab_exchange_mode(world)
+        exchange = {1: "level-0 charge all-gather", 2: "level-0 charge halo exchange + level-1 all-gather"}.get(m, str(m))
+        exchange += " (collectives: %s)" % type(stepper.coll).__name__
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -134,7 +152,7 @@ def main():
 
     pairs = N * (4.0 * math.pi / 3.0) * abar ** 3 / world   # ordered in-cutoff pairs handled by one rank's launch
     flops = pairs * FLOP_PER_PAIR[p]
-    pair_s = acc_ms.get("pair_kernel", acc_ms["pairs"]) * 1e-3
+    pair_s = (acc_ms.get("pair_kernel") or acc_ms.get("pairs") or acc_ms.get("total", 0.0)) * 1e-3
     achieved = flops / pair_s / 1e12 if pair_s > 0 else 0.0
 
     cpu = parity = None
@@ -144,15 +162,23 @@ def main():
         en_cpu = cpu_out["energies"]
         scale = float(np.abs(en_cpu[:6]).max())
         da = acc_gpu - cpu_out["acc"]
-        parity = {"energy_max_abs_diff_over_largest_component": float(np.abs(en_gpu - en_cpu).max() / scale),
+        parity = {"system": "the unperturbed benchmark system (the timed steps displace it)",
+                  "energy_max_abs_diff_over_largest_component": float(np.abs(en_gpu - en_cpu).max() / scale),
+                  "largest_component": scale,
                   "utotal_gpu": float(en_gpu[6]), "utotal_cpu": float(en_cpu[6]),
+                  "utotal_rel_diff": float(abs(en_gpu[6] - en_cpu[6]) / abs(en_cpu[6])),
                   "acc_rel_rms_diff": float(np.sqrt((da ** 2).sum() / (cpu_out["acc"] ** 2).sum())),
-                  "tolerance": 1e-12}
+                  "tolerance": 1e-12,
+                  "tolerance_note": "1e-12 of the largest energy component and 1e-12 relative RMS of the accelerations; the "
+                                    "total is what cancellation leaves of components up to sixty times larger, so relative "
+                                    "to itself it is held to 1e-10"}
     accuracy = None
     if rank == 0 and world == 1 and not args.no_accuracy:
         accuracy = ewald_accuracy(torch, msm_amd, r_all, q_all, A, ref_eval[0], ref_eval[1], dev)
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pair_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_pair_traffic.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r01_pair_traffic.json")
     if world == 1 and os.path.exists(tpath):
         with open(tpath) as f:
             traffic = json.load(f).get("order%d" % p, {}).get("hbm_bytes_per_launch")
@@ -175,7 +201,7 @@ def main():
                                    "abar=4, mu=10, grid %s, %d levels + Fourier top (kmax=%d)"
                                    % (N, p, "x".join(str(m) for m in desc.M), desc.L, desc.kmax),
                        "particles": N, "order": p, "levels": desc.L, "grid": list(desc.M),
-                       "parallelism": "single GPU" if world == 1 else "z-slabs x%d, level-0 charge all-gather" % world,
+                       "parallelism": "single GPU" if world == 1 else "z-slabs x%d, %s" % (world, exchange),
                        **({} if backend == "nccl" else {"rehearsal": "ranks share devices, %s collectives through the host: not a measurement" % backend})},
             "roofline": {"kernel": "k_pair_clusters_filtered (short-range pair sum)", "bound": "valu_fp64", "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
@@ -183,7 +209,9 @@ def main():
                          "note": "FP64 vector FMA bound (the FP64 MFMA peak is the same 78.6 TF); algorithmic flops = "
                                  "N*(4pi/3)*abar^3 ordered pairs x %d flop" % FLOP_PER_PAIR[p]},
             "kernel_ms": acc_ms,
-            "energies": dict(zip(capi.U_NAMES, [float(x) for x in energies])) if energies is not None else None,
+            "energies_last_timed_step": dict(zip(capi.U_NAMES, [float(x) for x in energies])) if energies is not None else None,
+            "energies_note": "of the last timed step, whose positions are the benchmark system displaced by up to 5e-5; the "
+                             "unperturbed system is the one in `parity` and `accuracy`",
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
@@ -288,18 +316,40 @@ class SlabProfiler:
                 e = t.cuda.Event(enable_timing=True)
                 e.record()
                 evs.append((name, e))
+            eng = self.slab.eng
+            if hasattr(eng, "set_profiling"):
+                eng.set_profiling(True)      # brackets the pair kernel with its own events
             self.slab.step(marks=mark)
             t.cuda.synchronize()
             for (name, e0), (_, e1) in zip(evs[:-1], evs[1:]):
                 acc[name] = acc.get(name, 0.0) + e0.elapsed_time(e1) / n
             acc["total"] = acc.get("total", 0.0) + evs[0][1].elapsed_time(evs[-1][1]) / n
+            if hasattr(eng, "set_profiling"):
+                try:
+                    acc["pair_kernel"] = acc.get("pair_kernel", 0.0) + eng.last_kernel_ms("pair_kernel") / n
+                except Exception:
+                    pass
+                eng.set_profiling(False)
         return acc
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(desc, r, q):
-    """The CPU oracle (oracle/msm_spec.c: the same mathematics as the GPU path, C + OpenMP) on this box."""
+    """The CPU oracle (oracle/msm_spec.c: the same mathematics as the GPU path, C + OpenMP) on this box's cores, and
+    the reference's own algorithm on one core in the only regime it can run (N <= 512)."""
     import oracle_lib as O
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    # the cores this job may use: the box exports its share as OMP_NUM_THREADS (os.cpu_count() is the whole machine)
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
     sp = O.SpecPlan.explicit(desc.N, list(desc.A), list(desc.M), desc.p, desc.mu, desc.L, desc.a, desc.beta, desc.kmax,
                              nthreads=cores)
     t0 = time.perf_counter()
@@ -307,9 +357,64 @@ def cpu_baseline(desc, r, q):
     dt = time.perf_counter() - t0
     names = ("pairs", "anterpolation", "restriction", "convolution", "top", "prolongation", "interpolation", "total")
     return {"value": 1.0 / dt, "unit": "evals/s", "cores": cores, "kind": "port",
+            "host": {"cpu_model": cpu_model(), "cpus_of_the_machine": os.cpu_count(), "cpus_used": cores},
             "sample": "1 evaluation of the same %d-particle system (all stages)" % desc.N,
+            "note": "an unoptimised port: its anterpolation alone takes more than half of the time",
             "stage_seconds": dict(zip(names, [float(x) for x in out["seconds"]])),
-            "utotal": float(out["energies"][6])}, out
+            "utotal": float(out["energies"][6]),
+            "reference_literal": reference_literal_timings()}, out
+
+
+def reference_literal_timings():
+    """The reference's algorithm itself, single-threaded as the reference is (msmPeriodic.c:52, "time total" of
+    msmLibrary.c:337), on the systems of msm/data it can execute: the literal mirror oracle/msm_literal.c (stage for stage
+    the reference's arithmetic; its image sums are tabulated, so its stencil set-up is faster than the reference's) at
+    N = 8, 64, 512, and - when the reference itself was built into oracle/_ref - the real msmPeriodic at N = 8 and 64
+    with its own clock() split between stencil set-up and everything else."""
+    import subprocess
+    import tempfile
+    import oracle_lib as O
+    res = {"cores": 1, "mirror": {}, "reference_binary": {}}
+    for name in ("changaN8", "changaN64", "changaN512"):
+        fx = O.golden("msmPeriodic_%s.json" % name)
+        sysd = fx["system"]
+        rr, qq = np.array(sysd["r"]).reshape(-1, 3), np.array(sysd["q"])
+        t0 = time.perf_counter()
+        lit = O.literal_run(rr, qq, 4, 4.0, 10, sysd["L"])
+        dt = time.perf_counter() - t0
+        res["mirror"][name] = {"N": sysd["N"], "seconds": dt, "evals_per_s": 1.0 / dt, "utotal": float(lit["u_total"]),
+                               "reference_recorded_seconds": float(fx["stats"]["time total"])}
+    exe = os.path.join(ROOT, "oracle", "_ref", "msmPeriodic")
+    if os.path.exists(exe):
+        for name in ("changaN8", "changaN64"):
+            fx = O.golden("msmPeriodic_%s.json" % name)
+            sysd = fx["system"]
+            rr, qq = np.array(sysd["r"]).reshape(-1, 3), np.array(sysd["q"])
+            with tempfile.TemporaryDirectory() as tmp:
+                path = os.path.join(tmp, name + ".txt")
+                with open(path, "w") as f:
+                    f.write("%.17g %.17g %.17g\n%d\n" % (sysd["L"][0], sysd["L"][1], sysd["L"][2], sysd["N"]))
+                    for i in range(sysd["N"]):
+                        f.write("%.17g %.17g %.17g %.17g\n" % (rr[i, 0], rr[i, 1], rr[i, 2], qq[i]))
+                try:
+                    t0 = time.perf_counter()
+                    out = subprocess.run([exe, path, "4", "10", "4"], cwd=tmp, capture_output=True, text=True, timeout=120)
+                    dt = time.perf_counter() - t0
+                except (subprocess.TimeoutExpired, OSError) as e:
+                    res["reference_binary"][name] = {"error": str(e)}
+                    continue
+            st = {}
+            for ln in out.stdout.splitlines():
+                if len(ln) > 31 and ln[:30].strip().startswith("time "):
+                    st[ln[:30].strip()] = float(ln[31:].strip())
+            total, sten = st.get("time total", dt), st.get("time stencill", 0.0) + st.get("time stencilL", 0.0)
+            res["reference_binary"][name] = {"N": sysd["N"], "wall_seconds": dt, "time_total": total, "stencil_setup": sten,
+                                             "without_stencil_setup": total - sten,
+                                             "evals_per_s_with_setup": 1.0 / total,
+                                             "evals_per_s_without_setup": 1.0 / max(total - sten, 1e-9)}
+    else:
+        res["reference_binary"] = "oracle/_ref/msmPeriodic is not built on this machine"
+    return res
 
 
 if __name__ == "__main__":

@@ -749,8 +749,8 @@ __global__ __launch_bounds__(256) void k_pair_clusters(ClusterGeom g, ClusterBuf
 // within the cutoff of some particle of i, so the wave first tests the 64 particles of 8 listed clusters against
 // the bounding box of i (one particle per lane), compacts the survivors into a queue in LDS, and runs the pair
 // arithmetic on groups of 8 survivors (lane = (ii, jj), jj picks the survivor): about 40 % fewer pair slots for
-// one cheap test per listed particle.  The box test uses the same floating-point expression as the pair distance
-// with |component| no larger, so it can never drop a pair the arithmetic would have kept.  The queue is private
+// one cheap test per listed particle.  The box test runs in single precision against a cutoff and a box widened by
+// more than the rounding of the converted coordinates, so it can never drop a pair the arithmetic would have kept.  The queue is private
 // to the wave; survivors keep list order, so the sum order is fixed.  Energy bookkeeping as in k_pair_clusters.
 #define CLQ_CAP 128 // queue entries per wave: fewer than 64 pending + 64 new
 #define CLQ_U 4 // groups per unrolled step of the pair arithmetic (2..4 and 4..6 waves per SIMD all time the same)
@@ -790,20 +790,25 @@ __global__ __launch_bounds__(256) void k_pair_clusters_filtered(ClusterGeom g, C
     cl_slot<P, true>(I.x, I.y, I.z, b.ps[(size_t)CL_G * icl + jj], pp, ii != jj, uh, fx, fy, fz);
 
     // the 64 particles of 8 list entries, one per lane: survivors of the box test are appended to the queue
-    // (box as centre and half extent, widened by far more than the rounding of the centre form)
+    // (box as centre and half extent)
     const double bcx = 0.5 * (il.x + ih.x), bcy = 0.5 * (il.y + ih.y), bcz = 0.5 * (il.z + ih.z);
     const double bhx = 0.5 * (ih.x - il.x) + 1e-13 * g.A[0], bhy = 0.5 * (ih.y - il.y) + 1e-13 * g.A[1],
                  bhz = 0.5 * (ih.z - il.z) + 1e-13 * g.A[2];
+    const float fcx = (float)bcx, fcy = (float)bcy, fcz = (float)bcz;
+    const float fhx = (float)bhx * 1.000001f + 1e-6f * (float)g.A[0], fhy = (float)bhy * 1.000001f + 1e-6f * (float)g.A[1],
+                fhz = (float)bhz * 1.000001f + 1e-6f * (float)g.A[2];
     auto filter = [&](unsigned ent, double4 p, bool shifted) {
         if (shifted) {
             double sx, sy, sz;
             shift_of_code(g, (int)(ent >> CL_CODE_SHIFT), sx, sy, sz);
             p.x += sx; p.y += sy; p.z += sz;
         }
-        const double dx = fmax(fabs(p.x - bcx) - bhx, 0.0);
-        const double dy = fmax(fabs(p.y - bcy) - bhy, 0.0);
-        const double dz = fmax(fabs(p.z - bcz) - bhz, 0.0);
-        const bool keep = fma(dx, dx, fma(dy, dy, dz * dz)) < pp.a2;
+        // in single precision (half the issue cost of the double-precision form: 3 % of the kernel), against a cutoff and
+        // half extents widened by more than the rounding of the converted coordinates (at most 2e-7 of the cell edge)
+        const float dxf = fmaxf(fabsf((float)p.x - fcx) - fhx, 0.f);
+        const float dyf = fmaxf(fabsf((float)p.y - fcy) - fhy, 0.f);
+        const float dzf = fmaxf(fabsf((float)p.z - fcz) - fhz, 0.f);
+        const bool keep = fmaf(dxf, dxf, fmaf(dyf, dyf, dzf * dzf)) < g.a2_wide;
         const unsigned long long m = __ballot(keep);
         const int pos = tail + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         if (keep) Q[pos] = p;

@@ -1322,6 +1322,16 @@ extern "C" int msm_amd_last_timings(msm_amd_handle *h, double ms[10]) {
 
 extern "C" int msm_amd_last_kernel_ms(msm_amd_handle *h, const char *name, double *ms) {
     if (!h || !name || !ms) return MSM_AMD_EINVAL;
+    if (!strcmp(name, "pair_kernel") && h->pk_recorded && h->ev_made) {
+        // the pair kernel's own pair of events, read once they have completed (msm_amd_slab_step leaves them unread)
+        float t = 0;
+        if (hipEventSynchronize(h->ev_pk[1]) == hipSuccess && hipEventElapsedTime(&t, h->ev_pk[0], h->ev_pk[1]) == hipSuccess) {
+            h->pair_kernel_ms = t;
+            *ms = t;
+            return MSM_AMD_OK;
+        }
+        (void)hipGetLastError();
+    }
     if (!strcmp(name, "pair_kernel") && h->pair_kernel_ms >= 0.0) { *ms = h->pair_kernel_ms; return MSM_AMD_OK; }
     set_error("last_kernel_ms: no timing for %s in the last profiled evaluation", name);
     return MSM_AMD_EINVAL;
