@@ -327,8 +327,11 @@ void msm_amd_rccl_destroy(msm_amd_collectives *c);
 enum {
     MSM_AMD_SLAB_AUTO = 0,      /* halo exchange when it is possible and moves less than the all-gather */
     MSM_AMD_SLAB_ALLGATHER = 1, /* every rank gets the whole level-0 charge grid (one collective; coarse levels solved redundantly) */
-    MSM_AMD_SLAB_HALO = 2       /* p/2 + (stencil half width) planes from each z neighbour, level-1 charges all-gathered;
+    MSM_AMD_SLAB_HALO = 2,      /* p/2 + (stencil half width) planes from each z neighbour, level-1 charges all-gathered;
                                    needs L >= 2, an even number of owned planes, and halos that fit the neighbours' slabs */
+    MSM_AMD_SLAB_REDUCE = 3     /* open-boundary plans, whose slabs are cut where the particles are and so differ in size: every
+                                   rank clears the planes it does not own and the level-0 charge grid is summed over the
+                                   ranks (adding zeros is exact, so this is a gather); chosen by itself for such plans */
 };
 /* What msm_amd_slab_step would do for this handle and world size under `mode` (one of the two concrete values), or a
  * negative error when `mode` asks for a halo exchange the plan cannot do. */

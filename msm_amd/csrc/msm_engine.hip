@@ -1111,6 +1111,13 @@ extern "C" int msm_amd_slab_exchange_mode(msm_amd_handle *h, int world, int mode
     const int Mz = d.M[2], nz = d.nzplanes, H = slab_halo_planes(h);
     const bool can_halo = d.L >= 2 && world >= 2 && H > 0 && nz % 2 == 0 && d.zplane0 % 2 == 0 && H <= nz && nz + 2 * H <= Mz &&
                           (long)nz * world == Mz && !h->hp.literal && !d.open_boundary;
+    if (d.open_boundary) {
+        if (mode == MSM_AMD_SLAB_HALO || mode == MSM_AMD_SLAB_ALLGATHER) {
+            set_error("slab step: an open-boundary plan exchanges its level-0 charges by a sum over the ranks only");
+            return MSM_AMD_EINVAL;
+        }
+        return MSM_AMD_SLAB_REDUCE;
+    }
     if (mode == MSM_AMD_SLAB_HALO) {
         if (can_halo) return MSM_AMD_SLAB_HALO;
         set_error("slab step: a halo exchange needs L >= 2, an even number of owned planes (%d) and %d halo planes per side "
@@ -1139,7 +1146,7 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
     if (slab) {
         xmode = msm_amd_slab_exchange_mode(h, world, mode);
         if (xmode < 0) return xmode;
-        if ((long)d.nzplanes * world != d.M[2] || d.zplane0 != coll->rank * d.nzplanes) {
+        if (xmode != MSM_AMD_SLAB_REDUCE && ((long)d.nzplanes * world != d.M[2] || d.zplane0 != coll->rank * d.nzplanes)) {
             set_error("msm_amd_slab_step: rank %d of %d must own planes [%d, %d) of %d", coll->rank, world, coll->rank * (d.M[2] / world),
                       (coll->rank + 1) * (d.M[2] / world), d.M[2]);
             return MSM_AMD_EINVAL;
@@ -1166,7 +1173,18 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
         h->stream = b; // the helpers enqueue on the handle's stream
         double *q0 = h->gq[0];
         rc = 0;
-        if (xmode == MSM_AMD_SLAB_ALLGATHER) {
+        if (xmode == MSM_AMD_SLAB_REDUCE) {
+            // slabs of different thickness: clear what this rank does not own, then sum over the ranks
+            const size_t below = plane * d.zplane0, above = plane * (d.M[2] - d.zplane0 - d.nzplanes);
+            if ((below && hipMemsetAsync(q0, 0, below * sizeof(double), b) != hipSuccess) ||
+                (above && hipMemsetAsync(q0 + plane * (d.zplane0 + d.nzplanes), 0, above * sizeof(double), b) != hipSuccess)) {
+                set_error("slab step: clearing the planes of other ranks failed");
+                rc = MSM_AMD_EHIP;
+            } else if (coll->all_reduce_sum(coll->ctx, q0, plane * d.M[2], (void *)b)) {
+                set_error("slab step: the sum of the level-0 charges over the ranks failed");
+                rc = MSM_AMD_EHIP;
+            }
+        } else if (xmode == MSM_AMD_SLAB_ALLGATHER) {
             if (coll->all_gather(coll->ctx, q0 + plane * d.zplane0, q0, plane * d.nzplanes, (void *)b)) {
                 set_error("slab step: the all-gather of the level-0 charges failed");
                 rc = MSM_AMD_EHIP;

@@ -416,8 +416,8 @@ int build_host_plan(HostPlan &hp, const StencilBackend *be) {
             return MSM_AMD_EINVAL;
         }
     }
-    if (d.open_boundary && (hp.literal || d.nzplanes != d.M[2])) {
-        set_error("open-boundary plans have no literal mode and no slab decomposition");
+    if (d.open_boundary && hp.literal) {
+        set_error("open-boundary plans have no literal mode");
         return MSM_AMD_EINVAL;
     }
     if (d.open_boundary && (long)(d.M[0] >> (d.L - 1)) * (d.M[1] >> (d.L - 1)) * (d.M[2] >> (d.L - 1)) > 48L * 48 * 48) {

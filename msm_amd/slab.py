@@ -150,6 +150,31 @@ def select_slab(r, Az, Mz, world, rank, halo):
     return np.nonzero(owned)[0], np.nonzero(halo_mask)[0]
 
 
+def open_slab_edges(r, desc, world):
+    """Plane boundaries e[0] = 0 <= e[1] <= ... <= e[world] = Mz of an open-boundary plan, cut so that every rank owns
+    about the same number of particles (the cell is padded: planes at either end hold none).  Deterministic in the
+    positions, so every rank computes the same cut."""
+    Mz = desc.M[2]
+    zg = (np.asarray(r)[:, 2] - desc.origin[2]) / desc.A[2] * Mz      # grid units
+    cuts = np.quantile(zg, np.arange(1, world) / world)
+    e = [0] + [int(round(c)) for c in cuts] + [Mz]
+    for k in range(1, world):                                          # strictly increasing, at least one plane each
+        e[k] = min(max(e[k], e[k - 1] + 1), Mz - (world - k))
+    return e
+
+
+def select_open_slab(r, desc, edges, rank, halo):
+    """Owned and halo particle indices of `rank` for an open-boundary plan: no periodic images along z."""
+    Mz = desc.M[2]
+    zg = (np.asarray(r)[:, 2] - desc.origin[2]) / desc.A[2] * Mz
+    lo, hi = edges[rank], edges[rank + 1]
+    owner = np.clip(np.searchsorted(np.asarray(edges[1:-1], dtype=np.float64), zg, side="right"), 0, len(edges) - 2)
+    owned = owner == rank
+    hg = halo / desc.A[2] * Mz
+    halo_mask = (~owned) & (zg >= lo - hg) & (zg < hi + hg)
+    return np.nonzero(owned)[0], np.nonzero(halo_mask)[0]
+
+
 def halo_width(desc, margin=0.0):
     hz = desc.A[2] / desc.M[2]
     return max(desc.a, (desc.p / 2) * hz) + margin
@@ -167,8 +192,15 @@ class SlabRank:
     def __init__(self, torch, dist, msm_amd, desc, r_all, q_all, rank, world, local_rank=0, margin=2e-4,
                  engine_factory=None, perturb=False, headroom=1.02, mode=capi.SLAB_AUTO, collectives=None, c_step=True):
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
-        self.z0, self.nz = slab_planes(desc.M[2], world, rank)
-        own, hal = select_slab(r_all, desc.A[2], desc.M[2], world, rank, halo_width(desc, margin if perturb else 0.0))
+        self.open = bool(getattr(desc, "open_boundary", 0))
+        if self.open:
+            # slabs cut by particle count; the level-0 charges are summed over the ranks (msm_amd_slab_step)
+            self.edges = open_slab_edges(r_all, desc, world)
+            self.z0, self.nz = self.edges[rank], self.edges[rank + 1] - self.edges[rank]
+            own, hal = select_open_slab(r_all, desc, self.edges, rank, halo_width(desc, margin if perturb else 0.0))
+        else:
+            self.z0, self.nz = slab_planes(desc.M[2], world, rank)
+            own, hal = select_slab(r_all, desc.A[2], desc.M[2], world, rank, halo_width(desc, margin if perturb else 0.0))
         self.own_idx, self.halo_idx = own, hal
         n_own, n_tot = len(own), len(own) + len(hal)
         d = copy.copy(desc)
@@ -213,6 +245,9 @@ class SlabRank:
         positions; every rank sends each of its owned particles to the new owner and to every rank whose halo it
         falls in, owned records before halo records, so a receiver holds [owned from rank 0, 1, ... | halo from rank
         0, 1, ...].  Two collectives: all-to-all of the counts, all-to-all of the records."""
+        if self.open:
+            raise ValueError("SlabRank.exchange() is for periodic plans: an open-boundary plan is rebuilt around the new "
+                             "positions (msm_amd_plan_open), which moves the slab cuts too")
         t, W = self.torch, self.world
         n = self.n_own
         r, q, gid = self.r[:n], self.q[:n], self.gid[:n]
@@ -297,6 +332,8 @@ class SlabRank:
         if self.perturb:
             self.r.add_(self.delta, alpha=self.sign)
             self.sign = -self.sign
+        if self.open and self.coll is None:
+            raise ValueError("open-boundary slabs need the C step (msm_amd_slab_step)")
         if self.coll is not None:
             mark("step")
             eng.slab_step(self.coll.ptr, self.r, self.q, self.acc, self.mode)

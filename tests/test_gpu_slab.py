@@ -230,3 +230,61 @@ def test_rccl_collectives_single_rank():
     assert torch.equal(acc1, acc2)          # pair part + grid part: the same two numbers added either way
     eng.close()
     lib.msm_amd_rccl_destroy(p)
+
+
+def _open_worker(rank, world, port, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)
+    import torch
+    import torch.distributed as dist
+    import msm_amd
+    from msm_amd.slab import SlabRank
+    from test_gpu_parity import open_system
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, p, mu, h, a, L = OPEN_SLAB
+    r, q = open_system(N, 5, (1.0, 0.8, 1.3), (0.3, -0.2, 5.0))
+    desc = msm_amd.plan_open(N, r.min(axis=0), r.max(axis=0), p, mu, h, a, L)
+    sr = SlabRank(torch, dist, msm_amd, desc, r, q, rank, world, local_rank=0)
+    for _ in range(2):
+        en = sr.step()
+    np.savez(os.path.join(out_dir, "open%d.npz" % rank), en=en, idx=sr.own_idx, acc=sr.owned_acc().cpu().numpy(),
+             z0=sr.z0, nz=sr.nz, used=sr.eng.slab_exchange_mode(world))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+OPEN_SLAB = (30000, 6, 10, 1.0 / 32, 0.125, 3)
+
+
+def test_open_boundary_slabs_match_single_gpu(tmp_path):
+    """The non-periodic MSM (msm3d, msmLibrary.h:216) over four ranks sharing cuda:0: slabs cut by particle count (the
+    padding planes of the cell hold none), level-0 charges summed over the ranks, everything else as in the periodic
+    slab step; energies and accelerations equal the one-GPU evaluation of the same plan."""
+    import torch.multiprocessing as mp
+    import msm_amd
+    from test_gpu_parity import open_system
+    world = 4
+    mp.spawn(_open_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    N, p, mu, h, a, L = OPEN_SLAB
+    r, q = open_system(N, 5, (1.0, 0.8, 1.3), (0.3, -0.2, 5.0))
+    desc = msm_amd.plan_open(N, r.min(axis=0), r.max(axis=0), p, mu, h, a, L)
+    eng = msm_amd.Engine(desc)
+    en1, acc1 = eng.eval(r, q)
+    acc1 = acc1.cpu().numpy()
+    acc = np.zeros((N, 3))
+    seen = np.zeros(N, dtype=int)
+    scale = np.abs(en1[:6]).max()
+    planes, counts = 0, []
+    for k in range(world):
+        z = np.load(os.path.join(str(tmp_path), "open%d.npz" % k))
+        acc[z["idx"]] = z["acc"]
+        seen[z["idx"]] += 1
+        assert int(z["used"]) == 3 and int(z["z0"]) == planes
+        planes += int(z["nz"])
+        counts.append(len(z["idx"]))
+        assert np.abs(z["en"] - en1).max() < 1e-12 * scale, (k, z["en"], en1)
+    assert planes == desc.M[2] and (seen == 1).all()
+    assert max(counts) < 1.2 * min(counts), counts            # balanced by particle count, not by planes
+    assert np.sqrt(((acc - acc1) ** 2).sum() / (acc1 ** 2).sum()) < 1e-12

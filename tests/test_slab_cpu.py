@@ -225,3 +225,33 @@ def test_direct_rows_partition():
             assert all(cuts[k][1] == cuts[k + 1][0] for k in range(world - 1))
             sizes = [b - a for a, b in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_open_slab_partition_is_exact_and_balanced():
+    """Open-boundary slabs: plane cuts by particle count; every particle owned once; halo copies are exactly the
+    particles within the halo distance of the slab (no periodic images)."""
+    import msm_amd
+    from msm_amd.slab import open_slab_edges, select_open_slab
+    rng = np.random.default_rng(9)
+    N = 20000
+    r = rng.random((N, 3)) * np.array([1.0, 0.7, 1.6]) + np.array([2.0, -1.0, 40.0])
+    r[: N // 4, 2] = 40.0 + 0.2 * rng.random(N // 4)          # a dense layer: equal-thickness slabs would be lopsided
+    desc = msm_amd.plan_open(N, r.min(axis=0), r.max(axis=0), 4, 10, 1.0 / 24, 4.0 / 24, 2)
+    for world in (2, 3, 8):
+        e = open_slab_edges(r, desc, world)
+        assert e[0] == 0 and e[-1] == desc.M[2] and all(b > a for a, b in zip(e[:-1], e[1:]))
+        seen = np.zeros(N, dtype=int)
+        counts = []
+        halo = 4.0 / 24
+        zg = (r[:, 2] - desc.origin[2]) / desc.A[2] * desc.M[2]
+        for k in range(world):
+            own, hal = select_open_slab(r, desc, e, k, halo)
+            seen[own] += 1
+            counts.append(len(own))
+            assert not np.intersect1d(own, hal).size
+            assert ((zg[own] >= e[k]) | (k == 0)).all() and ((zg[own] < e[k + 1]) | (k == world - 1)).all()
+            hg = halo / desc.A[2] * desc.M[2]
+            want = np.nonzero((seen * 0 == 0) & ~np.isin(np.arange(N), own) & (zg >= e[k] - hg) & (zg < e[k + 1] + hg))[0]
+            assert np.array_equal(np.sort(hal), want)
+        assert (seen == 1).all()
+        assert max(counts) < 1.35 * (N / world), counts        # cuts fall on planes, so not perfectly even
