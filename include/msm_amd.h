@@ -338,9 +338,9 @@ enum {
 int msm_amd_slab_exchange_mode(msm_amd_handle *h, int world, int mode);
 
 /* One evaluation of the particles this rank holds (msm_amd_set_counts: the first n_owned of them owned, the rest halo
- * copies): sort -> [pair sum on the handle's stream] beside [anterpolation of the owned planes -> exchange -> grid levels ->
- * interpolation on a second stream] -> raw sums -> all-reduce.  d_acc[3 n_total] receives the accelerations of the
- * owned particles.  The call queues everything and returns; the reduced sums stay on the device until
+ * copies): sort -> anterpolation of the owned planes -> [exchange of the level-0 charges on a second stream] beside
+ * [neighbour lists and pair sum on the handle's stream] -> grid levels -> interpolation -> raw sums -> all-reduce.
+ * d_acc[3 n_total] receives the accelerations of the owned particles.  The call queues everything and returns; the reduced sums stay on the device until
  * msm_amd_slab_energies reads them.  coll == NULL (or world == 1 with a full-grid handle): no exchange, the handle
  * must own every plane. */
 int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *coll, const double *d_r, const double *d_q, double *d_acc,
