@@ -1395,6 +1395,8 @@ bool launch_conv_tiled(hipStream_t st, const double *q, const double *Kt, const 
 // tile and feeds R * SZ FMAs whose stencil taps are wave-uniform (scalar loads).  With one wave per SIMD (the
 // tile takes almost all of the LDS) nothing else hides latency, so the window and the taps of the next
 // (sx, sy) are requested before the FMAs of the current one are issued.
+typedef __attribute__((address_space(4))) double ctap_t; // stencil taps: constant for the kernel, uniform per wave
+
 template <int SZ, int R, int TX, int TY, int TZ, int CH>
 __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
     extern __shared__ double lds[];
@@ -1428,7 +1430,9 @@ __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
     for (int cube = 0; cube < ncube; cube++) {
     const int ca = cube % c.nsub, cb = (cube / c.nsub) % c.nsub, cc = cube / (c.nsub * c.nsub);
     const int ox = X0 - (c.kf[0] + ca * SZ + SZ - 1), oy = Y0 - (c.kf[1] + cb * SZ + SZ - 1), oz = Z0 - (c.kf[2] + cc * SZ + SZ - 1);
-    const double *__restrict__ Kt = B.Kt[lev] + (size_t)cube * (SZ * SZ * SZ);
+    // the taps are the same for every lane: read through the constant address space they come as scalar loads into
+    // SGPRs and leave the vector memory path to the staging loads
+    const ctap_t *Kt = (const ctap_t *)(B.Kt[lev] + (size_t)cube * (SZ * SZ * SZ));
     const int gx0 = modp(ox + hl, Mx), gx1 = modp(ox + hl + 32, Mx);
     const int sy_lo = c.sy0, sy_hi = c.sy1 > 0 ? c.sy1 : SZ; // the share of the taps this launch entry applies
     for (int c0 = sy_lo; c0 < sy_hi; c0 += CHR) {
@@ -1437,31 +1441,33 @@ __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
         const int rows = TY + nch - 1;
         if (c0 > sy_lo || cube > 0) __syncthreads();
         {
-            // staging: half a wave per (z, y) row of the tile, lanes along x; the periodic wrap is done once per
-            // row (no integer division per element), and the loads of 8 rows are issued before the first store
-            constexpr int NH = NT / 32, BATCH = 8;
-            int ly = half, lz = 0; // row = lz * rows + ly, advanced by NH per step
-            while (ly >= rows) { ly -= rows; lz++; }
-            while (lz < LZ) {
-                double v0[BATCH], v1[BATCH];
-                int sly[BATCH], slz[BATCH];
+            // staging: half a wave per z plane of the tile, lanes along x, one y row after the other.  The wrapped y
+            // of a row is the same for every lane (scalar arithmetic); the wrapped z is found once per plane; the
+            // loads of a batch of rows are issued before the first store.
+            constexpr int NH = NT / 32;
+            constexpr int BATCH = TY + CHR - 1 <= 12 ? TY + CHR - 1 : 8;
+            const int yw0 = modp(oy + ys, My);
+            for (int lz = half; lz < LZ; lz += NH) {
+                const double *pl = q + (size_t)modp(oz + lz, Mz) * ((size_t)My * Mx);
+                double *lrow = lds + lz * plane + hl * LY;
+                int yw = yw0;
+                for (int b = 0; b < rows; b += BATCH) {
+                    double v0[BATCH], v1[BATCH];
 #pragma unroll
-                for (int k = 0; k < BATCH; k++) {
-                    sly[k] = ly; slz[k] = lz;
-                    v0[k] = v1[k] = 0.0;
-                    if (lz < LZ) {
-                        const size_t rowbase = ((size_t)modp(oz + lz, Mz) * My + modp(oy + ys + ly, My)) * Mx;
-                        if (hl < LX) v0[k] = q[rowbase + gx0];
-                        if (LX > 32 && hl + 32 < LX) v1[k] = q[rowbase + gx1];
+                    for (int k = 0; k < BATCH; k++) {
+                        if (b + k < rows) {
+                            const double *row = pl + (size_t)yw * Mx;
+                            if (hl < LX) v0[k] = row[gx0];
+                            if (LX > 32 && hl + 32 < LX) v1[k] = row[gx1];
+                        }
+                        yw = yw + 1 == My ? 0 : yw + 1;
                     }
-                    ly += NH;
-                    while (ly >= rows) { ly -= rows; lz++; }
-                }
 #pragma unroll
-                for (int k = 0; k < BATCH; k++) {
-                    if (slz[k] < LZ) {
-                        if (hl < LX) lds[(slz[k] * LX + hl) * LY + sly[k]] = v0[k];
-                        if (LX > 32 && hl + 32 < LX) lds[(slz[k] * LX + hl + 32) * LY + sly[k]] = v1[k];
+                    for (int k = 0; k < BATCH; k++) {
+                        if (b + k < rows) {
+                            if (hl < LX) lrow[b + k] = v0[k];
+                            if (LX > 32 && hl + 32 < LX) lrow[32 * LY + b + k] = v1[k];
+                        }
                     }
                 }
             }
@@ -1472,7 +1478,7 @@ __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
         double vc[W], kc[SZ]; // window and taps of the current (sx, sy)
         {
             const double *col = colc - c0;
-            const double *kk = Kt + (size_t)c0 * SZ * SZ;
+            const ctap_t *kk = Kt + (size_t)c0 * SZ * SZ;
 #pragma unroll
             for (int w = 0; w < W; w++) vc[w] = col[w * plane];
 #pragma unroll
@@ -1492,7 +1498,7 @@ __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
                     const bool last = sx == SZ - 1;
                     // after the last tap of a pass there is nothing to fetch: any valid address will do
                     const double *col = last ? colc - (more ? sy + 1 : sy) : colc - ((sx + 1) * LY + sy);
-                    const double *kk = Kt + (size_t)(last ? (more ? (sy + 1) * SZ : sy * SZ) : sy * SZ + sx + 1) * SZ;
+                    const ctap_t *kk = Kt + (size_t)(last ? (more ? (sy + 1) * SZ : sy * SZ) : sy * SZ + sx + 1) * SZ;
                     constexpr int WH = (W + 1) / 2;
                     const double *colb = col + WH * plane;
 #pragma unroll
