@@ -134,6 +134,8 @@ struct TileSrc {
 // A/B choices of the tile kernels, kept per handle
 struct SplineOpts {
     int interp_threads = 256;       // threads of a tile workgroup of the interpolation kernel (multiple of 64, at most 512)
+    int interp_split = 0;           // workgroups that share the particles of a tile (0 = one)
+    int interp_remap = 1;           // whole-grid evaluations: an XCD takes a contiguous run of tiles
     int anterp_cols_waves = 0;      // waves per tile workgroup of the column kernel: 4, 8, 16, or 0 = by the share of owned planes
     bool anterp_cols_order4 = false; // the column kernel at order 4 too
     bool anterp_cols = true;        // register accumulation per column (cluster order, columns up to 2 x 2 cells)

@@ -327,11 +327,13 @@ __global__ __launch_bounds__(256) void k_anterp_combine(const double *__restrict
 // nodes out of LDS.  acc_i += f sum_m e_m grad Phi_m(r_i), f by the acceleration convention.
 template <int P>
 __global__ __launch_bounds__(512) void k_interp_tiles(TileSrc S, SplineParams sp, TileGeom tl, const double *__restrict__ e,
-                                                      double *__restrict__ acc) {
+                                                      double *__restrict__ acc, int remap) {
     constexpr int R = AT + P - 1, R3 = R * R * R;
     __shared__ double blk[R3];
     __shared__ int rowstart[AT * AT + 1], rowbase[AT * AT];
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    // Whole grid: an XCD gets a contiguous run of tiles, whose blocks of potentials overlap.  A rank that owns a slab
+    // has its particles in a contiguous run of tiles: those are dealt out over the XCDs one by one instead.
+    const int tile = remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int tx = tile % tl.nt[0], ty = (tile / tl.nt[0]) % tl.nt[1], tz = tile / (tl.nt[0] * tl.nt[1]);
     const int Mx = sp.M[0], My = sp.M[1], Mz = sp.M[2];
     const int x0 = tx * AT, y0 = ty * AT, z0 = tz * AT;
@@ -431,12 +433,13 @@ __global__ __launch_bounds__(512) void k_interp_tiles(TileSrc S, SplineParams sp
 
 void launch_interp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, const double *egrid,
                          double *acc, const SplineOpts &opt) {
-    // gridDim.y > 1 shares a tile's particles between workgroups; measured slower even for a rank that owns a thin
-    // slab (every workgroup stages the tile's block of potentials again), so one workgroup per tile it is
-    const int ns = 1;
-    const int nthreads = opt.interp_threads;
-    if (sp.p == 4) hipLaunchKernelGGL((k_interp_tiles<4>), dim3(tl.ntiles, ns), dim3(nthreads), 0, st, S, sp, tl, egrid, acc);
-    else hipLaunchKernelGGL((k_interp_tiles<6>), dim3(tl.ntiles, ns), dim3(nthreads), 0, st, S, sp, tl, egrid, acc);
+    const int ns = opt.interp_split ? opt.interp_split : 1;
+    const bool slab = sp.nz < sp.M[2];
+    // a slab rank has few busy tiles: more threads to each
+    const int nthreads = slab ? std::max(512, opt.interp_threads) : opt.interp_threads;
+    const int remap = !slab && opt.interp_remap;
+    if (sp.p == 4) hipLaunchKernelGGL((k_interp_tiles<4>), dim3(tl.ntiles, ns), dim3(nthreads), 0, st, S, sp, tl, egrid, acc, remap);
+    else hipLaunchKernelGGL((k_interp_tiles<6>), dim3(tl.ntiles, ns), dim3(nthreads), 0, st, S, sp, tl, egrid, acc, remap);
 }
 
 bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, double *scratch,
