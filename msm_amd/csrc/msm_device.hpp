@@ -22,6 +22,14 @@ __device__ __forceinline__ int modp(int i, int M) {
     return r < 0 ? r + M : r;
 }
 
+// i mod M for an i that is almost always within one period of [0, M): two selects, and the division only for the rest
+__device__ __forceinline__ int wrapm(int i, int M) {
+    i = (i < 0) ? i + M : i;
+    i = (i >= M) ? i - M : i;
+    if (i < 0 || i >= M) i = modp(i, M);
+    return i;
+}
+
 // Column number of column (cx, cy): tiles of 8 x 8 columns, tile after tile.  Clusters are numbered in column
 // order and waves take clusters in that order, so the waves in flight at any time work on a compact patch of
 // columns and find their neighbours' particles in L2 instead of fetching them once per row of columns.

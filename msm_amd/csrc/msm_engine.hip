@@ -89,6 +89,7 @@ struct msm_amd_handle {
     hipStream_t stream_b = nullptr;
     hipStream_t stream_g = nullptr; // coarse-level branch of the grid stage
     hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr;
+    int opt_conv_groups = 1;  // slab ranks: the level-0 convolution by k_conv_split
     int opt_grid_streams = 0; // measured: slower (1.68 vs 1.65 ms at 1M; the chain of small kernels does not get CUs while the
                               // level-0 convolution runs), and cross-stream waits stalled with 4 processes sharing one GPU
     hipEvent_t ev_fork = nullptr, ev_pairs = nullptr, ev_join = nullptr;
@@ -515,6 +516,7 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "conv_small")) { h->opt_conv_small = value; return MSM_AMD_OK; }
     if (!strcmp(key, "anterp_tiled")) { h->opt_anterp_tiled = value; return MSM_AMD_OK; }
     if (!strcmp(key, "interp_threads")) { if (value >= 64 && value <= 512 && value % 64 == 0) { h->sopt.interp_threads = value; return MSM_AMD_OK; } }
+    if (!strcmp(key, "conv_groups")) { h->opt_conv_groups = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "interp_remap")) { h->sopt.interp_remap = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "interp_split")) { if (value >= 0 && value <= 16) { h->sopt.interp_split = value; return MSM_AMD_OK; } }
     if (!strcmp(key, "anterp_cols_waves")) { if (value == 0 || value == 4 || value == 8 || value == 16) { h->sopt.anterp_cols_waves = value; return MSM_AMD_OK; } }
@@ -698,6 +700,7 @@ static void convolve_ranges(msm_amd_handle *h, const std::vector<PlaneRange> &ra
     if (!h->hp.literal && h->opt_conv_tiled >= 2) {
         ConvBatch B;
         B.n = 0;
+        B.split = h->opt_conv_groups;
         std::vector<size_t> members;
         // A slab rank convolves a few planes of level 0: fewer tiles (16 x 8 x 16 outputs each) than the chip has CUs,
         // so the kernel lasts as long as one workgroup needs for all taps of its tile.  The taps are then shared out

@@ -993,7 +993,7 @@ void launch_prolong3_add(hipStream_t st, const double *coarse, double *fine, con
 // launches, and every value is formed by the same operations in the same order as in the separate passes.
 // (The same construction for the prolongation was measured slower than its three separate passes.)
 #define TR_T 4         // coarse nodes per tile edge: small tiles, so that even a 24^3 grid gives every CU work
-#define TR_THREADS 128
+#define TR_THREADS 256
 template <int H>
 __global__ __launch_bounds__(TR_THREADS) void k_restrict_tiled(const double *__restrict__ fine, double *__restrict__ coarse, Transfer3 t) {
     constexpr int NF = 2 * TR_T - 1 + 2 * H; // fine nodes per axis under a tile of coarse nodes
@@ -1005,11 +1005,14 @@ __global__ __launch_bounds__(TR_THREADS) void k_restrict_tiled(const double *__r
     // x: t1[zi][yi][xc] = sum_j J|j| fine[2 (X0 + xc) + j, 2 Y0 - H + yi, 2 Z0 - H + zi]
     for (int o = threadIdx.x; o < NF * NF * TR_T; o += TR_THREADS) {
         const int xc = o % TR_T, yi = (o / TR_T) % NF, zi = o / (TR_T * NF);
-        const double *row = fine + ((size_t)modp(2 * Z0 - H + zi, t.Mf[2]) * t.Mf[1] + modp(2 * Y0 - H + yi, t.Mf[1])) * t.Mf[0];
+        const double *row = fine + ((size_t)modp(2 * Z0 - H + zi, t.Mf[2]) * t.Mf[1] + wrapm(2 * Y0 - H + yi, t.Mf[1])) * t.Mf[0];
         const int m = X0 + xc;
+        double v[2 * H + 1]; // (all loads of the element before the first use)
+#pragma unroll
+        for (int j = -H; j <= H; j++) v[j + H] = row[wrapm(2 * m + j, t.Mf[0])];
         double s = 0.0;
 #pragma unroll
-        for (int j = -H; j <= H; j++) s = fma(t.J[j < 0 ? -j : j], row[modp(2 * m + j, t.Mf[0])], s);
+        for (int j = -H; j <= H; j++) s = fma(t.J[j < 0 ? -j : j], v[j + H], s);
         t1[zi][yi][xc] = s;
     }
     __syncthreads();
@@ -1037,8 +1040,9 @@ __global__ __launch_bounds__(TR_THREADS) void k_restrict_tiled(const double *__r
 // out[n] = sum_{|j| <= H, n - j even} J|j| in[(n - j) / 2].  Small tiles (8^3 fine nodes): with large ones a grid
 // has fewer tiles than the chip has CUs and the three dependent passes of a workgroup are not hidden by anything.
 #define PR_T 8 // fine nodes per tile edge
+#define PR_THREADS 256
 template <int H>
-__global__ __launch_bounds__(128) void k_prolong_tiled(const double *__restrict__ coarse, double *__restrict__ fine, Transfer3 t) {
+__global__ __launch_bounds__(PR_THREADS) void k_prolong_tiled(const double *__restrict__ coarse, double *__restrict__ fine, Transfer3 t) {
     constexpr int TF = PR_T, NC = PR_T / 2 + 4; // coarse nodes per axis that reach a tile: X0/2 - 2 .. X0/2 + TF/2 + 1 (H <= 3)
     constexpr int NP = NC + 1;
     __shared__ double t1[TF][NC][NP]; // [z fine][y coarse][x coarse]
@@ -1048,21 +1052,21 @@ __global__ __launch_bounds__(128) void k_prolong_tiled(const double *__restrict_
     const int ZT = (blockIdx.x / (ntx * nty)) * TF, Z0 = t.z0 + ZT; // may be negative or run past the grid: taken modulo
     const int cx0 = X0 / 2 - 2, cy0 = Y0 / 2 - 2;
     const size_t plane = (size_t)t.Mc[0] * t.Mc[1];
-    for (int o = threadIdx.x; o < TF * NC * NC; o += 128) {
+    for (int o = threadIdx.x; o < TF * NC * NC; o += PR_THREADS) {
         const int xi = o % NC, yi = (o / NC) % NC, zf = o / (NC * NC);
-        const double *col = coarse + (size_t)modp(cy0 + yi, t.Mc[1]) * t.Mc[0] + modp(cx0 + xi, t.Mc[0]);
-        const int n = Z0 + zf;
+        const double *col = coarse + (size_t)wrapm(cy0 + yi, t.Mc[1]) * t.Mc[0] + wrapm(cx0 + xi, t.Mc[0]);
+        const int n = modp(Z0 + zf, t.Mf[2]); // the plane itself: its coarse neighbours are then one wrap away at most
         double s = 0.0;
 #pragma unroll
         for (int j = -H; j <= H; j++) {
             const int u = n - j;
             if (u & 1) continue;
-            s = fma(t.J[j < 0 ? -j : j], col[(size_t)modp(u / 2, t.Mc[2]) * plane], s);
+            s = fma(t.J[j < 0 ? -j : j], col[(size_t)wrapm(u >> 1, t.Mc[2]) * plane], s);
         }
         t1[zf][yi][xi] = s;
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < TF * TF * NC; o += 128) {
+    for (int o = threadIdx.x; o < TF * TF * NC; o += PR_THREADS) {
         const int xi = o % NC, yf = (o / NC) % TF, zf = o / (NC * TF);
         const int n = Y0 + yf;
         double s = 0.0;
@@ -1075,7 +1079,7 @@ __global__ __launch_bounds__(128) void k_prolong_tiled(const double *__restrict_
         t2[zf][yf][xi] = s;
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < TF * TF * TF; o += 128) {
+    for (int o = threadIdx.x; o < TF * TF * TF; o += PR_THREADS) {
         const int xf = o % TF, yf = (o / TF) % TF, zf = o / (TF * TF);
         if (X0 + xf >= t.Mf[0] || Y0 + yf >= t.Mf[1] || ZT + zf >= t.nz) continue;
         const int n = X0 + xf;
@@ -1095,8 +1099,8 @@ void launch_prolong_tiled_add(hipStream_t st, const double *coarse, double *fine
     Transfer3 t = make_transfer(Mf, p, J);
     t.z0 = z0; t.nz = nz; // fine planes [z0, z0 + nz) modulo Mf[2]
     const int nb = ((t.Mf[0] + PR_T - 1) / PR_T) * ((t.Mf[1] + PR_T - 1) / PR_T) * ((nz + PR_T - 1) / PR_T);
-    if (p == 4) hipLaunchKernelGGL((k_prolong_tiled<2>), dim3(nb), dim3(128), 0, st, coarse, fine, t);
-    else hipLaunchKernelGGL((k_prolong_tiled<3>), dim3(nb), dim3(128), 0, st, coarse, fine, t);
+    if (p == 4) hipLaunchKernelGGL((k_prolong_tiled<2>), dim3(nb), dim3(PR_THREADS), 0, st, coarse, fine, t);
+    else hipLaunchKernelGGL((k_prolong_tiled<3>), dim3(nb), dim3(PR_THREADS), 0, st, coarse, fine, t);
 }
 
 void launch_restrict_tiled(hipStream_t st, const double *fine, double *coarse, const int Mf[3], int p, const double J[4], int z0,
@@ -1559,9 +1563,154 @@ static bool conv_multi_launch(hipStream_t st, ConvBatch &B) {
     return true;
 }
 
+// The same convolution for a rank that owns a slab: few planes of level 0, so fewer 16 x 8 x 16 tiles than the chip
+// has CUs and a launch as long as one tile takes.  Tiles of 16 x 8 x 8 outputs, and G groups of two waves to a tile
+// that share the stencil's columns sx between them (same LDS tile, a G-th of the taps each): partial sums meet in
+// LDS at the end and are added in the order of the groups.  Four waves per SIMD hide what k_conv_multi hides by
+// prefetching, so the loop is the plain one.
+
+template <int SZ, int G, int CH>
+__global__ __launch_bounds__(128 * G, 4) void k_conv_split(ConvBatch B) {
+    constexpr int R = 8, TX = 16, TY = 8, TZ = 8;
+    extern __shared__ double lds[];
+    int lev = 0;
+    while (lev + 1 < B.n && (int)blockIdx.x >= B.blk0[lev + 1]) lev++;
+    const ConvArgs c = B.c[lev];
+    const double *__restrict__ q = B.q[lev];
+    double *__restrict__ e = B.e[lev];
+    const int ntx = B.ntx[lev], nty = B.nty[lev];
+    const int Mx = c.M[0], My = c.M[1], Mz = c.M[2];
+    constexpr int CHR = CH < SZ ? CH : SZ;
+    constexpr int LX = TX + SZ - 1, LY = ((TY + CHR - 1 + 1) / 4) * 4 + 2, LZ = TZ + SZ - 1;
+    static_assert(LX <= 32, "a row is staged by half a wave");
+    const int bid = blockIdx.x - B.blk0[lev];
+    const int bx = bid % ntx, by = (bid / ntx) % nty, bz = bid / (ntx * nty);
+    const int X0 = bx * TX, Y0 = by * TY, Z0 = c.z0 + bz * TZ;
+    constexpr int NT = 128 * G;
+    const int t128 = threadIdx.x & 127, tx = t128 % TX, ty = t128 / TX;
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
+    constexpr int SXG = (SZ + G - 1) / G;
+    const int sx0 = grp * SXG, nsx = min(SXG, SZ - sx0);
+    constexpr int W = R + SZ - 1;
+    constexpr int plane = LX * LY;
+    const int half = threadIdx.x >> 5, hl = threadIdx.x & 31;
+    double acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.0;
+    const int ncube = c.nsub * c.nsub * c.nsub;
+    const int sy_lo = c.sy0, sy_hi = c.sy1 > 0 ? c.sy1 : SZ;
+    for (int cube = 0; cube < ncube; cube++) {
+        const int ca = cube % c.nsub, cb = (cube / c.nsub) % c.nsub, cc = cube / (c.nsub * c.nsub);
+        const int ox = X0 - (c.kf[0] + ca * SZ + SZ - 1), oy = Y0 - (c.kf[1] + cb * SZ + SZ - 1), oz = Z0 - (c.kf[2] + cc * SZ + SZ - 1);
+        const ctap_t *Kt = (const ctap_t *)(B.Kt[lev] + (size_t)cube * (SZ * SZ * SZ));
+        const int gx0 = modp(ox + hl, Mx);
+        for (int c0 = sy_lo; c0 < sy_hi; c0 += CHR) {
+            const int nch = min(CHR, sy_hi - c0);
+            const int ys = SZ - c0 - nch;
+            const int rows = TY + nch - 1;
+            if (c0 > sy_lo || cube > 0) __syncthreads();
+            {
+                // staging as in k_conv_multi: half a wave per z plane, lanes along x, the rows one after the other
+                constexpr int NH = NT / 32, BATCH = TY + CHR - 1 <= 12 ? TY + CHR - 1 : 8;
+                const int yw0 = modp(oy + ys, My);
+                for (int lz = half; lz < LZ; lz += NH) {
+                    const double *pl = q + (size_t)modp(oz + lz, Mz) * ((size_t)My * Mx);
+                    double *lrow = lds + lz * plane + hl * LY;
+                    int yw = yw0;
+                    for (int b = 0; b < rows; b += BATCH) {
+                        double v0[BATCH];
+#pragma unroll
+                        for (int k = 0; k < BATCH; k++) {
+                            if (b + k < rows && hl < LX) v0[k] = pl[(size_t)yw * Mx + gx0];
+                            yw = yw + 1 == My ? 0 : yw + 1;
+                        }
+#pragma unroll
+                        for (int k = 0; k < BATCH; k++)
+                            if (b + k < rows && hl < LX) lrow[b + k] = v0[k];
+                    }
+                }
+            }
+            __syncthreads();
+            const double *colc = lds + (tx + SZ - 1) * LY + (ty + c0 + nch - 1);
+            for (int sy = c0; sy < c0 + nch; sy++) {
+#pragma unroll
+                for (int s = 0; s < SXG; s++) {
+                    if (s < nsx) {
+                        const int sx = sx0 + s;
+                        const double *col = colc - (sx * LY + sy);
+                        const ctap_t *kk = Kt + (size_t)(sy * SZ + sx) * SZ;
+                        double vc[W], kc[SZ];
+#pragma unroll
+                        for (int w = 0; w < W; w++) vc[w] = col[w * plane];
+#pragma unroll
+                        for (int z = 0; z < SZ; z++) kc[z] = kk[z];
+#pragma unroll
+                        for (int z = 0; z < SZ; z++)
+#pragma unroll
+                            for (int r = 0; r < R; r++) acc[r] = fma(kc[z], vc[r + SZ - 1 - z], acc[r]);
+                    }
+                }
+            }
+        }
+    }
+    // partial sums of the groups 1 .. G-1 through LDS (the tile is no longer needed), added in that order
+    __syncthreads();
+    if (grp > 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++) lds[((grp - 1) * R + r) * 128 + t128] = acc[r];
+    }
+    __syncthreads();
+    if (grp == 0) {
+        const int mx = X0 + tx, my = Y0 + ty;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            double v = acc[r];
+#pragma unroll
+            for (int g = 1; g < G; g++) v += lds[((g - 1) * R + r) * 128 + t128];
+            const int mz = Z0 + r;
+            if (mx < Mx && my < My && mz < c.z0 + c.nz && mz < Mz) e[((size_t)mz * My + my) * Mx + mx] = v;
+        }
+    }
+}
+
+template <int SZ, int G, int CH>
+static bool conv_split_launch(hipStream_t st, ConvBatch &B) {
+    constexpr int TX = 16, TY = 8, TZ = 8, CHR = CH < SZ ? CH : SZ;
+    constexpr int LX = TX + SZ - 1, LY = ((TY + CHR - 1 + 1) / 4) * 4 + 2, LZ = TZ + SZ - 1;
+    constexpr size_t bytes = sizeof(double) * (size_t)LX * LY * LZ;
+    static_assert(bytes <= 80 * 1024, "two workgroups to a CU");
+    static_assert(bytes >= sizeof(double) * (G - 1) * 8 * 128, "the partial sums fit the tile");
+    int nblk = 0;
+    for (int l = 0; l < B.n; l++) {
+        const ConvArgs &c = B.c[l];
+        if (c.ks[0] != SZ || c.ks[1] != SZ || c.ks[2] != SZ || c.nsub < 1) return false;
+        B.ntx[l] = (c.M[0] + TX - 1) / TX;
+        B.nty[l] = (c.M[1] + TY - 1) / TY;
+        B.blk0[l] = nblk;
+        nblk += B.ntx[l] * B.nty[l] * ((c.nz + TZ - 1) / TZ);
+    }
+    B.blk0[B.n] = nblk;
+    if (nblk == 0) return false;
+    auto kern = k_conv_split<SZ, G, CH>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(128 * G), bytes, st, B);
+    return true;
+}
+
 // tile 16 x 8 x 16 outputs, 8 per thread; CH = rows of sy per staging pass, the most the 160 KB of LDS hold
 bool launch_conv_multi(hipStream_t st, ConvBatch &B) {
     if (B.n < 1) return false;
+    if (B.split && B.c[0].nz < B.c[0].M[2]) { // a slab of planes
+        if (B.c[0].ks[2] == 15 && conv_split_launch<15, 4, 5>(st, B)) return true;
+        if (B.c[0].ks[2] == 13 && conv_split_launch<13, 4, 5>(st, B)) return true;
+    }
     switch (B.c[0].ks[2]) {
     case 7: return conv_multi_launch<7, 8, 16, 8, 16, 7>(st, B);
     case 9: return conv_multi_launch<9, 8, 16, 8, 16, 9>(st, B);

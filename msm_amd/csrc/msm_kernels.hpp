@@ -167,6 +167,7 @@ struct ConvArgs {
 // up to 8 convolutions (levels, or plane ranges of a level) that share one launch
 struct ConvBatch {
     int n;
+    int split = 0;       // a slab of planes on level 0: tiles of 8 planes whose stencil columns are shared out over wave groups
     int blk0[9];
     int ntx[8], nty[8];
     ConvArgs c[8];
