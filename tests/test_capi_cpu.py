@@ -167,6 +167,17 @@ def test_no_cpu_fallback(msm):
     assert np.isnan(u) and b"no CPU path" in msm.load().msm_amd_last_error()
     u, f = msm.direct(r, q)
     assert u == 0.0 and not f.any() and b"no CPU path" in msm.load().msm_amd_last_error()
+    # the multi-rank entry points: null handles are refused, and a communicator cannot be made without a device
+    lib = msm.load()
+    assert lib.msm_amd_slab_step(None, None, None, None, None, 0) == -1 and b"null argument" in lib.msm_amd_last_error()
+    assert lib.msm_amd_slab_exchange_mode(None, 8, 0) < 0
+    assert lib.msm_amd_slab_energies(None, None, (C.c_double * 16)()) == -1
+    ident = C.create_string_buffer(128)
+    if lib.msm_amd_rccl_unique_id(ident) == 0:   # librccl is present in the image
+        from msm_amd.capi import Collectives
+        coll = C.POINTER(Collectives)()
+        assert lib.msm_amd_rccl_create(ident, 0, 1, C.byref(coll)) < 0 and not coll
+        assert b"ncclCommInitRank" in lib.msm_amd_last_error()
 
 
 def test_plan_open(msm):
