@@ -189,6 +189,13 @@ enum {
 };
 void msm_amd_set_mode(int mode);
 int msm_amd_get_mode(void);
+/* Without a call of msm_amd_set_mode(), the environment variable MSM_AMD_MODE = literal | scalable | auto chooses (for
+ * drivers that are built unchanged).  The two modes return different quantities in fappr: literal mode the reference's
+ * (msmPeriodic.c:1158-1160 and 1364-1366: with the charge of particle i, and r shifted by +0.5 in the caller's array), scalable mode
+ * the acceleration of a unit charge at r_i.  msm_amd_last_call_mode() tells which one the last msmperiodic() call of
+ * the process used (MSM_AMD_MODE_LITERAL or MSM_AMD_MODE_SCALABLE; -1 before the first call); in auto mode the first
+ * call that takes the scalable path says so on stderr unless msm_amd_set_quiet(1). */
+int msm_amd_last_call_mode(void);
 /* msmperiodic(), msmPeriodicRunner() and msm3d() keep the plan of their last call (stencils and device buffers) and
  * reuse it when the next call needs the same one; this frees it. */
 void msm_amd_release_cached_plan(void);

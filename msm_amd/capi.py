@@ -107,6 +107,7 @@ SIGNATURES = {
     # handle layer
     "msm_amd_set_mode": (None, [C.c_int]),
     "msm_amd_get_mode": (C.c_int, []),
+    "msm_amd_last_call_mode": (C.c_int, []),
     "msm_amd_release_cached_plan": (None, []),
     "msm_amd_plan_builds": (C.c_long, []),
     "msm_amd_set_stencil_backend": (None, [C.c_int]),

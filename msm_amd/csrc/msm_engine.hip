@@ -120,8 +120,21 @@ extern "C" int msm_amd_get_stencil_backend(void) {
     }
     return g_stencils;
 }
-extern "C" void msm_amd_set_mode(int mode) { g_mode = mode; }
+static bool g_mode_set = false;   // msm_amd_set_mode() was called: the environment is not consulted
+static int g_last_call_mode = -1; // what the last msmperiodic() did: MSM_AMD_MODE_LITERAL or MSM_AMD_MODE_SCALABLE
+static bool g_auto_noticed = false;
+extern "C" void msm_amd_set_mode(int mode) { g_mode = mode; g_mode_set = true; }
 extern "C" int msm_amd_get_mode(void) { return g_mode; }
+extern "C" int msm_amd_last_call_mode(void) { return g_last_call_mode; }
+// mode of a msmperiodic() call: msm_amd_set_mode() if it was called, else MSM_AMD_MODE=literal|scalable|auto from the
+// environment (an unmodified driver has no other way to choose), else auto
+static int effective_mode() {
+    if (g_mode_set) return g_mode;
+    const char *e = getenv("MSM_AMD_MODE");
+    if (e && !strcmp(e, "literal")) return MSM_AMD_MODE_LITERAL;
+    if (e && !strcmp(e, "scalable")) return MSM_AMD_MODE_SCALABLE;
+    return g_mode;
+}
 extern "C" void msm_amd_set_quiet(int quiet) { g_quiet = quiet; }
 
 extern "C" int msm_amd_device_count(void) {
@@ -1524,7 +1537,15 @@ extern "C" msm_stats msmperiodic(int N, double *r, double *q, int p, double abar
     const double t_total = now_s();
     S.N = N;
     S.p = p;
-    const bool literal = g_mode == MSM_AMD_MODE_LITERAL || (g_mode == MSM_AMD_MODE_AUTO && N <= 4096);
+    const int mode = effective_mode();
+    const bool literal = mode == MSM_AMD_MODE_LITERAL || (mode == MSM_AMD_MODE_AUTO && N <= 4096);
+    g_last_call_mode = literal ? MSM_AMD_MODE_LITERAL : MSM_AMD_MODE_SCALABLE;
+    if (mode == MSM_AMD_MODE_AUTO && !literal && !g_quiet && !g_auto_noticed) {
+        // said once per process: the two modes return different quantities in fappr
+        g_auto_noticed = true;
+        fprintf(stderr, "msmperiodic: N = %d > 4096, scalable mode: fappr is the acceleration of a unit charge at r_i "
+                        "(no factor q_i), r is left as it is; msm_amd_set_mode() or MSM_AMD_MODE=literal|scalable chooses\n", N);
+    }
     if (literal && p != 4) { // msmPeriodic.c:100-104
         fprintf(stderr, "p must be 4\n");
         return S;

@@ -437,7 +437,39 @@ def test_dropin_keeps_its_plan(msm):
     en, acc = eng.eval_host(r2, q2)
     assert abs(u2 - en[6]) <= 1e-12 * np.abs(en[:6]).max() and rel_rms(f2, acc) < 1e-12
     eng.close()
+    assert lib.msm_amd_last_call_mode() == msm.capi.MODE_SCALABLE   # what the last msmperiodic() call did
     lib.msm_amd_release_cached_plan()
+
+
+def test_dropin_mode_from_the_environment(msm, tmp_path):
+    """A driver that never calls msm_amd_set_mode() chooses the mode with MSM_AMD_MODE; in auto mode the library says
+    once, on stderr, that a system above 4096 particles took the scalable path."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import msm_amd, oracle_lib as O
+        lib = msm_amd.capi.load()
+        r, q = O.neutral_system(%%d, (1.0, 1.0, 1.0), seed=3)
+        st, u, f, _ = msm_amd.msmperiodic(r.copy(), q, 4, 4.0, 10, (1.0, 1.0, 1.0), mode=None, quiet=%%d)
+        print("MODE", lib.msm_amd_last_call_mode(), repr(float(u)))
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    def run(n, env_mode, quiet=1):
+        env = dict(os.environ)
+        env.pop("MSM_AMD_MODE", None)
+        if env_mode:
+            env["MSM_AMD_MODE"] = env_mode
+        p = subprocess.run([sys.executable, "-c", code % (n, quiet)], env=env, capture_output=True, text=True, timeout=110,
+                           cwd=str(tmp_path))
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("MODE")][0].split()
+        return int(line[1]), float(line[2]), p.stderr
+    m_auto, u_auto, err = run(512, None)
+    assert m_auto == msm.capi.MODE_LITERAL and "scalable mode" not in err
+    m_sc, u_sc, _ = run(512, "scalable")
+    assert m_sc == msm.capi.MODE_SCALABLE and u_sc != u_auto   # (the literal index conventions are not the scalable ones)
+    m_big, _, err = run(5000, None, quiet=0)
+    assert m_big == msm.capi.MODE_SCALABLE and "scalable mode" in err
 
 
 def test_dropin_stagewise_literal(msm, torch):
