@@ -125,6 +125,49 @@ class HostStagedCollectives(_PythonCollectives):
         super().__init__(rank, world, guarded(all_gather), guarded(all_reduce_sum), guarded(halo_exchange))
 
 
+class TorchCollectives(_PythonCollectives):
+    """The table over a torch.distributed group that moves device memory (backend "nccl", i.e. RCCL): the fallback when
+    the library's own communicator cannot be made.  A call runs with the stream it is handed as torch's current stream,
+    so the process group orders its work after what that stream holds and the stream waits for the collective; the
+    host does not wait."""
+
+    def __init__(self, torch, dist, rank, world, device):
+        def view(ptr, count):
+            class _W:
+                pass
+            w = _W()
+            w.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+            return torch.as_tensor(w, device=device)
+
+        def on_stream(fn):
+            def call(*a):
+                try:
+                    ext = torch.cuda.ExternalStream(int(a[-1] or 0), device=device)
+                    with torch.cuda.stream(ext):
+                        fn(*a[:-1])
+                    return 0
+                except Exception:        # an exception must not unwind through the C caller
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return call
+
+        def all_gather(ctx, send, recv, count):
+            # (in place: `send` is this rank's share of `recv`, which the process group allows)
+            dist.all_gather_into_tensor(view(recv, count * world), view(send, count))
+
+        def all_reduce_sum(ctx, buf, count):
+            dist.all_reduce(view(buf, count))
+
+        def halo_exchange(ctx, send_up, send_down, recv_from_down, recv_from_up, count, up, down):
+            ops = [dist.P2POp(dist.isend, view(send_up, count), up), dist.P2POp(dist.irecv, view(recv_from_down, count), down),
+                   dist.P2POp(dist.isend, view(send_down, count), down), dist.P2POp(dist.irecv, view(recv_from_up, count), up)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+        super().__init__(rank, world, on_stream(all_gather), on_stream(all_reduce_sum), on_stream(halo_exchange))
+
+
 def slab_planes(Mz, world, rank):
     """First owned level-0 plane and the number of owned planes of `rank`."""
     if Mz % world != 0:
@@ -234,7 +277,21 @@ class SlabRank:
             if collectives is not None:
                 self.coll = collectives
             elif dist.get_backend() == "nccl":
-                self.coll = RcclCollectives(torch, dist, rank, world, dev)
+                # The library's own communicator; if any rank cannot make one, every rank takes the table over the
+                # process group instead (the ranks agree on that with one reduction, so that they never mix the two).
+                ok = 1
+                try:
+                    self.coll = RcclCollectives(torch, dist, rank, world, dev)
+                except Exception as e:  # noqa: BLE001 - whatever went wrong, the fallback is the same
+                    import sys
+                    print("msm_amd.slab: rank %d: %s; collectives through torch.distributed instead" % (rank, e), file=sys.stderr)
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    if self.coll is not None:
+                        self.coll.close()
+                    self.coll = TorchCollectives(torch, dist, rank, world, dev)
             else:
                 self.coll = HostStagedCollectives(torch, dist, rank, world, dev)
                 self.eng.set_option("slab_overlap", 0)   # ranks sharing a GPU: one stream per process

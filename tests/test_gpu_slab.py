@@ -232,6 +232,53 @@ def test_rccl_collectives_single_rank():
     lib.msm_amd_rccl_destroy(p)
 
 
+def test_torch_collectives_single_rank():
+    """The fallback table over a torch.distributed "nccl" group of one rank: a whole step through it equals the plain
+    evaluation (more ranks need more GPUs than this box has)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    import msm_amd
+    from msm_amd.slab import TorchCollectives
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        coll = TorchCollectives(torch, dist, 0, 1, torch.device("cuda:0"))
+        c = coll.ptr.contents
+        st = torch.cuda.Stream()
+        x = torch.arange(1000, dtype=torch.float64, device="cuda:0") + 0.5
+        y = torch.zeros(1000, dtype=torch.float64, device="cuda:0")
+        up, down = torch.zeros(64, dtype=torch.float64, device="cuda:0"), torch.zeros(64, dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        assert c.all_gather(c.ctx, x.data_ptr(), y.data_ptr(), 1000, st.cuda_stream) == 0
+        assert c.all_reduce_sum(c.ctx, x.data_ptr(), 1000, st.cuda_stream) == 0
+        assert c.halo_exchange(c.ctx, x[:64].data_ptr(), x[100:164].data_ptr(), down.data_ptr(), up.data_ptr(), 64, 0, 0, st.cuda_stream) == 0
+        st.synchronize()
+        torch.cuda.synchronize()
+        ref = torch.arange(1000, dtype=torch.float64) + 0.5
+        assert torch.equal(y.cpu(), ref) and torch.equal(x.cpu(), ref)
+        assert torch.equal(down.cpu(), ref[:64]) and torch.equal(up.cpu(), ref[100:164])
+        N = 20000
+        r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=5)
+        eng = msm_amd.Engine(msm_amd.plan_auto(N, (1.0, 1.0, 1.0), 6, 10, 4.0, 2))
+        rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
+        en1, acc1 = eng.eval(rd, qd)
+        acc1 = acc1.clone()
+        acc2 = torch.zeros_like(acc1)
+        eng.slab_step(coll.ptr, rd, qd, acc2)
+        en2 = eng.slab_energies(coll.ptr)
+        assert np.abs(en2 - en1).max() <= 1e-12 * np.abs(en1[:6]).max()
+        assert torch.equal(acc1, acc2)
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def _open_worker(rank, world, port, out_dir):
     import faulthandler
     faulthandler.dump_traceback_later(100, exit=True)
