@@ -1707,7 +1707,7 @@ static bool conv_split_launch(hipStream_t st, ConvBatch &B) {
 // tile 16 x 8 x 16 outputs, 8 per thread; CH = rows of sy per staging pass, the most the 160 KB of LDS hold
 bool launch_conv_multi(hipStream_t st, ConvBatch &B) {
     if (B.n < 1) return false;
-    if (B.split && B.c[0].nz < B.c[0].M[2]) { // a slab of planes
+    if (B.split > 1 || (B.split && B.c[0].nz < B.c[0].M[2])) { // a slab of planes (or on request)
         if (B.c[0].ks[2] == 15 && conv_split_launch<15, 4, 5>(st, B)) return true;
         if (B.c[0].ks[2] == 13 && conv_split_launch<13, 4, 5>(st, B)) return true;
     }
