@@ -189,18 +189,32 @@ __global__ __launch_bounds__(1024) void k_cs_blockscan(int *__restrict__ hist, i
     const int cx = threadIdx.x & 63, s = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     const int per = (nblk + 15) / 16, k0 = min(nblk, s * per), k1 = min(nblk, k0 + per);
+    // (eight loads in flight at a time: the loop is a chain of L2 round trips otherwise, and in the second pass the
+    // compiler cannot move a load of hist above a store to it by itself)
+    constexpr int B = 8;
     int sum = 0;
     if (c < ncols)
-        for (int k = k0; k < k1; k++) sum += hist[(size_t)k * ncols + c];
+        for (int k = k0; k < k1; k += B) {
+            int v[B];
+#pragma unroll
+            for (int j = 0; j < B; j++) v[j] = k + j < k1 ? hist[(size_t)(k + j) * ncols + c] : 0;
+#pragma unroll
+            for (int j = 0; j < B; j++) sum += v[j];
+        }
     seg[s][cx] = sum;
     __syncthreads();
     if (c >= ncols) return;
     int run = 0;
     for (int t = 0; t < s; t++) run += seg[t][cx];
-    for (int k = k0; k < k1; k++) {
-        const int v = hist[(size_t)k * ncols + c];
-        hist[(size_t)k * ncols + c] = run;
-        run += v;
+    for (int k = k0; k < k1; k += B) {
+        int v[B];
+#pragma unroll
+        for (int j = 0; j < B; j++) v[j] = k + j < k1 ? hist[(size_t)(k + j) * ncols + c] : 0;
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+            if (k + j < k1) hist[(size_t)(k + j) * ncols + c] = run;
+            run += v[j];
+        }
     }
     if (s == 15) coltotal[c] = run;
 }
