@@ -7,8 +7,8 @@ One "step" is one whole evaluation of the hot path on particles already resident
 short-range pair sum -> anterpolation -> restrictions -> per-level grid convolutions -> Fourier top level ->
 prolongations -> interpolation -> energy reductions (and, for N > 1 ranks, the level-0 charge all-gather and
 the energy all-reduce).  Position-independent setup (beta, kmax, omega', stencils, allocation, communicator)
-is outside the timed region.  Positions are perturbed between steps so nothing can be cached.  Evaluations
-are queued back to back (msm_amd_eval_enqueue): each one's energies are copied asynchronously into its own slot
+is outside the timed region.  Consecutive steps evaluate different (displaced) copies of the system, made
+beforehand, so nothing can be cached.  Evaluations are queued back to back (msm_amd_eval_enqueue): each one's energies are copied asynchronously into its own slot
 of a pinned host ring, and the host synchronises once at the end of the timed region.
 
 Workload (the configuration the headline metric is quoted on): 1,000,000 charge-neutral
@@ -250,6 +250,8 @@ def ewald_accuracy(torch, msm_amd, r_all, q_all, A, en_msm, acc_msm, dev):
 
 
 class SingleGpu:
+    POSITION_SETS = 16
+
     def __init__(self, torch, eng, r, q, dev):
         self.torch = torch
         self.eng = eng
@@ -258,19 +260,20 @@ class SingleGpu:
         self.acc = torch.empty_like(self.r)
         g = torch.Generator(device=dev)
         g.manual_seed(7)
-        # small pre-generated displacement, re-applied with alternating sign: positions change every step
-        self.delta = (torch.rand(self.r.shape, generator=g, dtype=torch.float64, device=dev) - 0.5) * 1e-4
-        self.sign = 1.0
+        # Consecutive steps evaluate different inputs: a few displaced copies of the system (up to 5e-5 per coordinate)
+        # made here, before the timed region, and evaluated in turn - inputs resident in HBM, no displacement kernel
+        # between the evaluations.
+        delta = (torch.rand(self.r.shape, generator=g, dtype=torch.float64, device=dev) - 0.5) * 1e-4
+        K = self.POSITION_SETS
+        self.r_sets = torch.stack([self.r + delta * (((k + 1) / K) * (1.0 if k % 2 == 0 else -1.0)) for k in range(K)])
         self.ring = torch.zeros((64, 7), dtype=torch.float64).pin_memory()
         self.nstep = 0
 
     def step(self):
         # queued without a host synchronisation: every evaluation's energies are copied to their own slot of a
         # pinned host ring, and the caller synchronises once (bench: at the end of the timed region)
-        self.r.add_(self.delta, alpha=self.sign)
-        self.sign = -self.sign
         slot = self.ring[self.nstep % self.ring.shape[0]]
-        self.eng.eval_enqueue(self.r, self.q, self.acc, slot)
+        self.eng.eval_enqueue(self.r_sets[self.nstep % self.POSITION_SETS], self.q, self.acc, slot)
         self.nstep += 1
 
     @property

@@ -227,10 +227,10 @@ class SlabRank:
     """One rank of a slab-decomposed evaluation.  `engine_factory(desc)` returns an object with the Engine
     interface (tests inject a CPU stand-in to exercise the partition and collective logic without a GPU).
 
-    perturb=True is a benchmarking device only (bench.py, tools/rank_sim.py): every step() then displaces the held
-    positions by up to margin/2, alternating in sign, so that no step repeats the previous one, and the halo is
-    widened by `margin` to keep every partner of a displaced particle.  The default leaves the caller's positions
-    alone."""
+    perturb=True is a benchmarking device only (bench.py, tools/rank_sim.py): every step() then evaluates the next of
+    a few pre-made copies of the held positions, each displaced by up to margin/2, so that no step repeats the previous
+    one, and the halo is widened by `margin` to keep every partner of a displaced particle.  The default leaves the
+    caller's positions alone."""
 
     def __init__(self, torch, dist, msm_amd, desc, r_all, q_all, rank, world, local_rank=0, margin=2e-4,
                  engine_factory=None, perturb=False, headroom=1.02, mode=capi.SLAB_AUTO, collectives=None, c_step=True):
@@ -263,11 +263,9 @@ class SlabRank:
         self.send = torch.empty_like(self.q0[self.z0:self.z0 + self.nz])
         self.sums = self.eng.raw_sums_tensor()
         self.perturb = perturb
+        self._n_all = len(q_all)
         if perturb:
-            g = torch.Generator(device=dev)
-            g.manual_seed(7 + rank)
-            self.delta = (torch.rand(self.r.shape, generator=g, dtype=torch.float64, device=dev) - 0.5) * margin
-            self.sign = 1.0
+            self._make_position_sets()
         self._pending = self._pending_work = self._energies = None
         # The real engine runs the whole step in C (msm_amd_slab_step: pair sum beside the grid branch on two streams,
         # collectives from a table); a stand-in engine (CPU tests of the partition logic) is driven stage by stage below.
@@ -295,6 +293,23 @@ class SlabRank:
             else:
                 self.coll = HostStagedCollectives(torch, dist, rank, world, dev)
                 self.eng.set_option("slab_overlap", 0)   # ranks sharing a GPU: one stream per process
+
+    POSITION_SETS = 16
+
+    def _make_position_sets(self):
+        """Benchmarking device: POSITION_SETS displaced copies of the held positions, made before any timed step, so
+        that consecutive steps evaluate different inputs without a displacement kernel between them.  The displacement
+        of a particle is a function of its global index (the same table on every rank), so halo copies move with
+        their owners; it is at most margin / 2."""
+        t = self.torch
+        g = t.Generator(device="cpu")
+        g.manual_seed(7)
+        table = (t.rand((self._n_all, 3), generator=g, dtype=t.float64) - 0.5) * self.margin
+        delta = table[self.gid.cpu()].to(self.r.device)
+        K = self.POSITION_SETS
+        self.r0 = self.r
+        self.r_sets = t.stack([self.r0 + delta * (((k + 1) / K) * (1.0 if k % 2 == 0 else -1.0)) for k in range(K)])
+        self._set = 0
 
     def exchange(self):
         """Particle migration and halo refresh after the owned particles have moved (self.r[:n_own] rewritten by the
@@ -356,10 +371,7 @@ class SlabRank:
         self.own_idx, self.halo_idx = ids[:n_own], ids[n_own:]
         self.eng.set_counts(n_tot, n_own)
         if self.perturb:
-            g = t.Generator(device=r.device)
-            g.manual_seed(7 + self.rank)
-            self.delta = (t.rand(self.r.shape, generator=g, dtype=t.float64, device=r.device) - 0.5) * self.margin
-            self.sign = 1.0
+            self._make_position_sets()
 
     def _host_staged(self):
         # a gloo group cannot move device memory: stage through the host (functional testing on one GPU)
@@ -387,8 +399,8 @@ class SlabRank:
         eng = self.eng
         mark = marks if marks is not None else (lambda name: None)
         if self.perturb:
-            self.r.add_(self.delta, alpha=self.sign)
-            self.sign = -self.sign
+            self.r = self.r_sets[self._set % self.POSITION_SETS]
+            self._set += 1
         if self.open and self.coll is None:
             raise ValueError("open-boundary slabs need the C step (msm_amd_slab_step)")
         if self.coll is not None:
