@@ -1169,17 +1169,19 @@ __global__ __launch_bounds__(256) void k_pair_clusters_overflow(ClusterGeom g, C
 }
 
 void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double *acc,
-                          double *epart, int variant, int n_total, hipEvent_t *ev, int max_wgs) {
+                          double *epart, int variant, int n_total, hipEvent_t *ev, int max_wgs, hipEvent_t after_lists) {
     const double a = sqrt(pp.a2);
     const int nblk = (g.max_clusters + 3) / 4;
     const int nwg = max_wgs > 0 ? std::min(nblk, max_wgs) : nblk; // workgroups of the list-walking kernel (it loops over its share)
     const int half = pp.n_owned >= n_total ? 1 : 0; // every particle owned: pair energies are taken from one side
     if (variant == 1) {
+        if (after_lists) hipEventRecord(after_lists, st); // no lists: nothing to wait for
         if (pp.p == 4) hipLaunchKernelGGL((k_pair_clusters_direct<4>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart, half);
         else hipLaunchKernelGGL((k_pair_clusters_direct<6>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart, half);
         return;
     }
     hipLaunchKernelGGL(k_cl_list, dim3(nblk), dim3(256), 0, st, g, b, a, pp.a2, pp.n_owned);
+    if (after_lists) hipEventRecord(after_lists, st); // lets another stream start beside the pair kernel, not beside the list build
 #define LAUNCH_PC(P, HALF, U)                                                                                  \
     do {                                                                                                       \
         if (ev) hipEventRecord(ev[0], st);                                                                     \

@@ -89,6 +89,7 @@ struct msm_amd_handle {
     hipStream_t stream_b = nullptr;
     hipStream_t stream_g = nullptr; // coarse-level branch of the grid stage
     hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr;
+    hipEvent_t pairs_after = nullptr; // set for one msm_amd_stage_pairs call: recorded between the list build and the pair kernel
     int opt_conv_groups = 1;  // slab ranks: the level-0 convolution by k_conv_split
     int opt_grid_streams = 0; // measured: slower (1.68 vs 1.65 ms at 1M; the chain of small kernels does not get CUs while the
                               // level-0 convolution runs), and cross-stream waits stalled with 4 processes sharing one GPU
@@ -613,7 +614,8 @@ extern "C" int msm_amd_stage_pairs(msm_amd_handle *h, double *d_acc) {
             launch_cluster_sort(h->stream, h->cur_r, h->cur_q, h->N, h->clg, h->clb, h->bin_of, h->arrival, h->slot_idx, h->scan_tmp);
         h->clusters_sorted = true;
         launch_pair_clusters(h->stream, h->clg, h->clb, h->pp, d_acc, h->epart, h->opt_pair_variant - 5, h->N,
-                             h->profiling ? h->ev_pk : nullptr, h->pair_wgs_now);
+                             h->profiling ? h->ev_pk : nullptr, h->pair_wgs_now, h->pairs_after);
+        h->pairs_after = nullptr;
         h->pk_recorded = h->profiling && h->opt_pair_variant != 6;
         h->nepart = h->clg.max_clusters;
     } else {
@@ -825,7 +827,9 @@ static int grid_front(msm_amd_handle *h, const msm_amd_collectives *coll) {
     return MSM_AMD_OK;
 }
 
-static int grid_stage(msm_amd_handle *h, bool front_done) {
+// part: 0 the whole stage; 1 only the branch of the coarser levels (restrictions, their convolutions, top level,
+// prolongations down to level 1); 2 only what is left after it (level-0 convolution, last prolongation)
+static int grid_stage(msm_amd_handle *h, bool front_done, int part = 0) {
     const msm_amd_plan_desc &d = h->hp.d;
     const int L = d.L, p = d.p;
     hipStream_t st = h->stream;
@@ -857,6 +861,25 @@ static int grid_stage(msm_amd_handle *h, bool front_done) {
     // chip) and everything on the coarser levels (a chain of small, latency-bound kernels: restrictions,
     // convolutions of levels >= 1, top level, prolongations down to level 1).  On two streams the chain runs in the
     // shadow of the large kernel; the arithmetic and its order are the same either way.
+    if (part && L >= 2) {
+        if (part == 1) {
+            mark(h, T_RES);
+            for (int l = front_done ? 1 : 0; l + 1 < L; l++) restrict_level(h, l, h->gq[l], h->gq[l + 1]);
+            convolve_ranges(h, coarse);
+            top_level(h);
+            for (int l = L - 2; l >= 1; l--) prolong_level_add(h, l, h->ge[l + 1], h->ge[l]);
+        } else {
+            mark(h, T_CONV);
+            convolve_ranges(h, fine);
+            mark(h, T_TOP);
+            mark(h, T_PRO);
+            if (slab && d.nzplanes + p < d.M[2]) prolong_level_add(h, 0, h->ge[1], h->ge[0], d.zplane0 - p / 2, d.nzplanes + p);
+            else prolong_level_add(h, 0, h->ge[1], h->ge[0]);
+        }
+        HIPCHK(hipGetLastError());
+        return MSM_AMD_OK;
+    }
+    if (part == 1) return MSM_AMD_OK; // a one-level plan has no coarse branch
     const bool two = h->opt_grid_streams && !h->hp.literal && L >= 2;
     if (two && !h->stream_g) {
         int prio_lo = 0, prio_hi = 0;
@@ -1027,7 +1050,38 @@ extern "C" int msm_amd_eval(msm_amd_handle *h, const double *d_r, const double *
     if (overlap && (rc = ensure_stream_b(h))) return rc;
     mark(h, T_BIN);
     if ((rc = msm_amd_stage_bin(h, d_r, d_q))) return rc;
-    if (overlap) {
+    if (overlap && h->opt_overlap >= 2) {
+        // The anterpolation (bound by the LDS port) beside the pair sum (bound by the FP64 pipe); 3: and the branch of
+        // the coarser grid levels (latency-bound kernels); 4: as 3, but the second stream starts when the neighbour lists
+        // are built (beside the list build the anterpolation takes twice its time).
+        const bool coarse_too = h->opt_overlap >= 3, after_lists = h->opt_overlap == 4;
+        hipStream_t a = h->stream;
+        if (!after_lists) HIPCHK(hipEventRecord(h->ev_fork, a));
+        mark(h, T_PAIR);
+        if (after_lists) h->pairs_after = h->ev_fork;
+        rc = msm_amd_stage_pairs(h, d_acc);
+        const bool forked = !after_lists || h->pairs_after == nullptr; // (a path without lists did not record the event)
+        h->pairs_after = nullptr;
+        if (rc) return rc;
+        if (!forked) HIPCHK(hipEventRecord(h->ev_fork, a));
+        HIPCHK(hipEventRecord(h->ev_pairs, a));
+        HIPCHK(hipStreamWaitEvent(h->stream_b, h->ev_fork, 0));
+        h->stream = h->stream_b;
+        mark(h, T_ANT);
+        rc = msm_amd_stage_anterpolate(h);
+        if (!rc && coarse_too) rc = grid_stage(h, false, 1);
+        hipError_t e = hipEventRecord(h->ev_join, h->stream_b);
+        h->stream = a;
+        if (rc) return rc;
+        if (e != hipSuccess) return MSM_AMD_EHIP;
+        HIPCHK(hipStreamWaitEvent(a, h->ev_join, 0));
+        if ((rc = coarse_too ? grid_stage(h, false, 2) : msm_amd_stage_grid(h))) return rc; // marks T_RES..T_PRO
+        mark(h, T_INT);
+        if ((rc = msm_amd_stage_interpolate(h, d_acc))) return rc;
+        mark(h, T_RED);
+        if ((rc = queue_energies(h))) return rc;
+        mark(h, T_TOTAL);
+    } else if (overlap) {
         hipStream_t a = h->stream;
         HIPCHK(hipEventRecord(h->ev_fork, a));
         HIPCHK(hipStreamWaitEvent(h->stream_b, h->ev_fork, 0));

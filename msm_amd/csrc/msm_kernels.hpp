@@ -108,8 +108,9 @@ void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, i
 // evaluates its candidates directly.  Clusters whose list overflowed list_stride are evaluated by the direct kernel.
 // ev (optional): two events recorded immediately before and after the list-walking kernel
 // max_wgs > 0 caps the workgroups of the list-walking kernel (variant 3), which then loops over its clusters
+// after_lists (optional): an event recorded between the list build and the pair kernel
 void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double *acc,
-                          double *epart, int variant, int n_total, hipEvent_t *ev, int max_wgs = 0);
+                          double *epart, int variant, int n_total, hipEvent_t *ev, int max_wgs = 0, hipEvent_t after_lists = nullptr);
 
 // ---- short range ----
 void launch_pair_cells(hipStream_t st, const double4 *ps, const int *cstart, const int *order, int ncell,

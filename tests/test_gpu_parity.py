@@ -596,11 +596,13 @@ def test_full_size_properties(msm, torch, p):
     # bitwise reproducible
     en2, acc2 = eng.eval(rd, qd)
     assert np.array_equal(en, en2) and np.array_equal(acc, acc2.cpu().numpy())
-    # the grid branch on a second stream beside the pair branch: same kernels, same order of every sum
-    eng.set_option("overlap", 1)
-    for _ in range(3):
-        en2, acc2 = eng.eval(rd, qd)
-        assert np.array_equal(en, en2) and np.array_equal(acc, acc2.cpu().numpy())
+    # parts of the grid branch on a second stream beside the pair branch (1: all of it, 2: the anterpolation, 3: and the
+    # coarse levels, 4: as 3, from the end of the list build): same kernels, same order of every sum
+    for mode in (1, 2, 3, 4):
+        eng.set_option("overlap", mode)
+        for _ in range(3):
+            en2, acc2 = eng.eval(rd, qd)
+            assert np.array_equal(en, en2) and np.array_equal(acc, acc2.cpu().numpy()), mode
     eng.set_option("overlap", 0)
     # the pair kernel variants agree at full size
     for v in (1, 2, 3, 4, 6, 7, 9, 8, 5):

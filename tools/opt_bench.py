@@ -26,6 +26,10 @@ for spec in sys.argv[1:] or [""]:
     ms = (time.perf_counter() - t0) / 20 * 1e3
     eng.set_profiling(True)
     eng.eval(rd, qd, acc)
-    t = eng.last_timings()
+    t = dict(eng.last_timings())
+    try:
+        t["pair_kernel"] = eng.last_kernel_ms("pair_kernel")
+    except Exception:
+        pass
     eng.set_profiling(False)
-    print(spec or "(defaults)", "ms/eval %.3f" % ms, {k: round(v, 3) for k, v in t.items()})
+    print(spec or "(defaults)", "ms/eval %.3f" % ms, {k: round(float(v), 3) for k, v in t.items()})
