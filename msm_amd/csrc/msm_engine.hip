@@ -90,6 +90,7 @@ struct msm_amd_handle {
     hipStream_t stream_g = nullptr; // coarse-level branch of the grid stage
     hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr;
     hipEvent_t pairs_after = nullptr; // set for one msm_amd_stage_pairs call: recorded between the list build and the pair kernel
+    int opt_transfer_chain = 1; // two prolongations per launch where the grids allow it
     int opt_conv_groups = 1;  // slab ranks: the level-0 convolution by k_conv_split
     int opt_grid_streams = 0; // measured: slower (1.68 vs 1.65 ms at 1M; the chain of small kernels does not get CUs while the
                               // level-0 convolution runs), and cross-stream waits stalled with 4 processes sharing one GPU
@@ -530,6 +531,7 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "conv_small")) { h->opt_conv_small = value; return MSM_AMD_OK; }
     if (!strcmp(key, "anterp_tiled")) { h->opt_anterp_tiled = value; return MSM_AMD_OK; }
     if (!strcmp(key, "interp_threads")) { if (value >= 64 && value <= 512 && value % 64 == 0) { h->sopt.interp_threads = value; return MSM_AMD_OK; } }
+    if (!strcmp(key, "transfer_chain")) { h->opt_transfer_chain = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "conv_groups")) { h->opt_conv_groups = value; return MSM_AMD_OK; } // 2: for whole grids too (A/B)
     if (!strcmp(key, "interp_remap")) { h->sopt.interp_remap = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "interp_split")) { if (value >= 0 && value <= 16) { h->sopt.interp_split = value; return MSM_AMD_OK; } }
@@ -703,6 +705,26 @@ static void prolong_level_add(msm_amd_handle *h, int l, const double *coarse, do
     launch_prolong_axis(h->stream, h->tmpA, fine, c2, 0, p, h->hp.J, 1);
 }
 
+// prolongations from the coarsest level down to level 1; two at a time where the grids allow it (the potentials of the
+// level in the middle then stay without the prolonged part, which nothing reads)
+static void prolong_to_level1(msm_amd_handle *h) {
+    const int L = h->hp.d.L;
+    int l = L - 2;
+    while (l >= 1) {
+        const int *Mf = h->hp.Ml[l - (l >= 2 ? 1 : 0)];
+        const bool chain = h->opt_transfer_chain && l >= 2 && !h->hp.literal && h->opt_transfer_fused >= 3 && Mf[0] % 4 == 0 &&
+                           Mf[1] % 4 == 0 && Mf[2] % 4 == 0;
+        if (chain) {
+            int m[3] = {Mf[0], Mf[1], Mf[2]};
+            launch_prolong_chain_add(h->stream, h->ge[l + 1], h->ge[l], h->ge[l - 1], m, h->hp.d.p, h->hp.J);
+            l -= 2;
+        } else {
+            prolong_level_add(h, l, h->ge[l + 1], h->ge[l]);
+            l -= 1;
+        }
+    }
+}
+
 namespace {
 struct PlaneRange { int l, z0, nz; };
 }
@@ -867,7 +889,7 @@ static int grid_stage(msm_amd_handle *h, bool front_done, int part = 0) {
             for (int l = front_done ? 1 : 0; l + 1 < L; l++) restrict_level(h, l, h->gq[l], h->gq[l + 1]);
             convolve_ranges(h, coarse);
             top_level(h);
-            for (int l = L - 2; l >= 1; l--) prolong_level_add(h, l, h->ge[l + 1], h->ge[l]);
+            prolong_to_level1(h);
         } else {
             mark(h, T_CONV);
             convolve_ranges(h, fine);
@@ -906,7 +928,7 @@ static int grid_stage(msm_amd_handle *h, bool front_done, int part = 0) {
     }
     top_level(h);
     if (!two) mark(h, T_PRO);
-    for (int l = L - 2; l >= 1; l--) prolong_level_add(h, l, h->ge[l + 1], h->ge[l]);
+    prolong_to_level1(h);
     if (two) {
         hipError_t e = hipEventRecord(h->ev_gjoin, h->stream_g);
         h->stream = st;

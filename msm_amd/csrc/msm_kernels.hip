@@ -1094,6 +1094,117 @@ __global__ __launch_bounds__(PR_THREADS) void k_prolong_tiled(const double *__re
         fine[idx] = fine[idx] + s;
     }
 }
+// Two prolongations in one launch: fine += P(mid + P(low)), for whole grids (fine Mf, mid Mf / 2, low Mf / 4).
+// A workgroup takes a tile of 8^3 fine nodes; the 8^3 mid nodes that reach it need 8^3 low nodes, so the first
+// prolongation is recomputed per tile in LDS (three passes, z y x), added to the mid values, and prolonged again from
+// there.  Every value is formed by the operations of k_prolong_tiled in the same order, so `fine` gets the bits of two
+// separate launches.  `mid` itself is left as it was (its nodes are in the footprints of other workgroups, which
+// must see the old values): nothing reads the potentials of an intermediate level after the prolongations.
+template <int H>
+__global__ __launch_bounds__(PR_THREADS) void k_prolong_chain(const double *__restrict__ low, const double *__restrict__ mid,
+                                                              double *__restrict__ fine, Transfer3 t) {
+    constexpr int TF = PR_T, NC = PR_T / 2 + 4, NP = NC + 1; // NC mid nodes per axis reach a tile, and NC low nodes reach those
+    __shared__ double a1[NC][NC][NP], a2[NC][NC][NP], m[NC][NC][NP]; // [z mid][y][x]
+    __shared__ double t1[TF][NC][NP], t2[TF][TF][NP];
+    const int Mm[3] = {t.Mf[0] / 2, t.Mf[1] / 2, t.Mf[2] / 2}, Ml[3] = {t.Mf[0] / 4, t.Mf[1] / 4, t.Mf[2] / 4};
+    const int ntx = (t.Mf[0] + TF - 1) / TF, nty = (t.Mf[1] + TF - 1) / TF;
+    const int X0 = (blockIdx.x % ntx) * TF, Y0 = ((blockIdx.x / ntx) % nty) * TF, Z0 = (blockIdx.x / (ntx * nty)) * TF;
+    const int cx0 = X0 / 2 - 2, cy0 = Y0 / 2 - 2, cz0 = Z0 / 2 - 2;          // first mid node of the footprint (even)
+    const int lx0 = cx0 / 2 - 2, ly0 = cy0 / 2 - 2, lz0 = cz0 / 2 - 2;       // first low node (cx0 / 2 is exact)
+    const size_t lplane = (size_t)Ml[0] * Ml[1];
+    // mid footprint = P(low): z
+    for (int o = threadIdx.x; o < NC * NC * NC; o += PR_THREADS) {
+        const int xi = o % NC, yi = (o / NC) % NC, zm = o / (NC * NC);
+        const double *col = low + (size_t)wrapm(ly0 + yi, Ml[1]) * Ml[0] + wrapm(lx0 + xi, Ml[0]);
+        const int n = modp(cz0 + zm, Mm[2]);
+        double s = 0.0;
+#pragma unroll
+        for (int j = -H; j <= H; j++) {
+            const int u = n - j;
+            if (u & 1) continue;
+            s = fma(t.J[j < 0 ? -j : j], col[(size_t)wrapm(u >> 1, Ml[2]) * lplane], s);
+        }
+        a1[zm][yi][xi] = s;
+    }
+    __syncthreads();
+    // y (unwrapped node numbers: the parity of a node survives the wrap, the grids being even)
+    for (int o = threadIdx.x; o < NC * NC * NC; o += PR_THREADS) {
+        const int xi = o % NC, ym = (o / NC) % NC, zm = o / (NC * NC);
+        const int n = cy0 + ym;
+        double s = 0.0;
+#pragma unroll
+        for (int j = -H; j <= H; j++) {
+            const int u = n - j;
+            if (u & 1) continue;
+            s = fma(t.J[j < 0 ? -j : j], a1[zm][(u >> 1) - ly0][xi], s);
+        }
+        a2[zm][ym][xi] = s;
+    }
+    __syncthreads();
+    // x, and the mid values themselves: m = mid + P(low)
+    for (int o = threadIdx.x; o < NC * NC * NC; o += PR_THREADS) {
+        const int xm = o % NC, ym = (o / NC) % NC, zm = o / (NC * NC);
+        const int n = cx0 + xm;
+        double s = 0.0;
+#pragma unroll
+        for (int j = -H; j <= H; j++) {
+            const int u = n - j;
+            if (u & 1) continue;
+            s = fma(t.J[j < 0 ? -j : j], a2[zm][ym][(u >> 1) - lx0], s);
+        }
+        const size_t idx = ((size_t)modp(cz0 + zm, Mm[2]) * Mm[1] + wrapm(cy0 + ym, Mm[1])) * Mm[0] + wrapm(cx0 + xm, Mm[0]);
+        m[zm][ym][xm] = mid[idx] + s;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < TF * NC * NC; o += PR_THREADS) {
+        const int xi = o % NC, yi = (o / NC) % NC, zf = o / (NC * NC);
+        const int n = Z0 + zf;
+        double s = 0.0;
+#pragma unroll
+        for (int j = -H; j <= H; j++) {
+            const int u = n - j;
+            if (u & 1) continue;
+            s = fma(t.J[j < 0 ? -j : j], m[(u >> 1) - cz0][yi][xi], s);
+        }
+        t1[zf][yi][xi] = s;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < TF * TF * NC; o += PR_THREADS) {
+        const int xi = o % NC, yf = (o / NC) % TF, zf = o / (NC * TF);
+        const int n = Y0 + yf;
+        double s = 0.0;
+#pragma unroll
+        for (int j = -H; j <= H; j++) {
+            const int u = n - j;
+            if (u & 1) continue;
+            s = fma(t.J[j < 0 ? -j : j], t1[zf][(u >> 1) - cy0][xi], s);
+        }
+        t2[zf][yf][xi] = s;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < TF * TF * TF; o += PR_THREADS) {
+        const int xf = o % TF, yf = (o / TF) % TF, zf = o / (TF * TF);
+        if (X0 + xf >= t.Mf[0] || Y0 + yf >= t.Mf[1] || Z0 + zf >= t.Mf[2]) continue;
+        const int n = X0 + xf;
+        double s = 0.0;
+#pragma unroll
+        for (int j = -H; j <= H; j++) {
+            const int u = n - j;
+            if (u & 1) continue;
+            s = fma(t.J[j < 0 ? -j : j], t2[zf][yf][(u >> 1) - cx0], s);
+        }
+        const size_t idx = ((size_t)(Z0 + zf) * t.Mf[1] + (Y0 + yf)) * t.Mf[0] + (X0 + xf);
+        fine[idx] = fine[idx] + s;
+    }
+}
+
+void launch_prolong_chain_add(hipStream_t st, const double *low, const double *mid, double *fine, const int Mf[3], int p,
+                              const double J[4]) {
+    Transfer3 t = make_transfer(Mf, p, J);
+    const int nb = ((t.Mf[0] + PR_T - 1) / PR_T) * ((t.Mf[1] + PR_T - 1) / PR_T) * ((t.Mf[2] + PR_T - 1) / PR_T);
+    if (p == 4) hipLaunchKernelGGL((k_prolong_chain<2>), dim3(nb), dim3(PR_THREADS), 0, st, low, mid, fine, t);
+    else hipLaunchKernelGGL((k_prolong_chain<3>), dim3(nb), dim3(PR_THREADS), 0, st, low, mid, fine, t);
+}
 void launch_prolong_tiled_add(hipStream_t st, const double *coarse, double *fine, const int Mf[3], int p, const double J[4], int z0,
                               int nz) {
     Transfer3 t = make_transfer(Mf, p, J);

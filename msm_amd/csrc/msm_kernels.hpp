@@ -182,6 +182,10 @@ void launch_restrict_tiled(hipStream_t st, const double *fine, double *coarse, c
                            int nz);
 void launch_prolong_tiled_add(hipStream_t st, const double *coarse, double *fine, const int Mf[3], int p, const double J[4], int z0,
                               int nz);
+// fine += P(mid + P(low)) for whole grids whose sizes are multiples of 4 (fine Mf, mid Mf / 2, low Mf / 4): the bits of two
+// launch_prolong_tiled_add calls in `fine`; `mid` is not updated
+void launch_prolong_chain_add(hipStream_t st, const double *low, const double *mid, double *fine, const int Mf[3], int p,
+                              const double J[4]);
 bool launch_conv_multi(hipStream_t st, ConvBatch &B);
 // coarsest level + Fourier level, both full-period, as offset tables Ta (sum) and Tb (Fourier part): ea = Ta * q, eb = Tb * q
 void launch_conv_small_pair(hipStream_t st, const double *q, const double *Ta, const double *Tb, const int M[3], double *ea,

@@ -1031,3 +1031,30 @@ def test_driver_prints_what_the_reference_prints(msm, tmp_path, name):
     assert abs(float(out.stdout.splitlines()[-1]) - fx["potential"]) <= TOL * scale
     for fn in ("msm.acclong", "msm.accshort", "msm.acc", "msm.pot"):
         assert (tmp_path / fn).exists()
+
+
+@pytest.mark.parametrize("p", [4, 6])
+def test_prolongation_chain_is_two_prolongations(msm, torch, p):
+    """Two prolongations per launch (k_prolong_chain) leave in the finer grid the bits of two separate launches; the
+    potentials of the level in between keep their own convolution only."""
+    N, A = 100000, (1.0, 1.0, 1.0)
+    r, q = O.neutral_system(N, A, seed=21)
+    desc = msm.plan_auto(N, A, p, 10, 4.0, 4)            # 48 -> 24 -> 12 -> 6
+    assert desc.L == 4
+    eng = msm.Engine(desc)
+    rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
+    out = {}
+    for chain in (1, 0):
+        eng.set_option("transfer_chain", chain)
+        en, acc = eng.eval(rd, qd)
+        out[chain] = (np.array(en), acc.cpu().numpy().copy(), [eng.grid(msm.capi.GRID_E, l).copy() for l in range(4)])
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    for l in (0, 1, 3):
+        assert np.array_equal(out[0][2][l], out[1][2][l]), l
+    assert not np.array_equal(out[0][2][2], out[1][2][2])   # level 2 without / with the part prolonged from level 3
+    # and the separate launches are what the oracle computes, level by level
+    sp = spec_for(desc)
+    sp.eval(r, q)
+    for l in range(4):
+        assert grid_err(out[0][2][l], sp.grid("e", l)) < TOL, l
+    eng.close()
