@@ -1818,7 +1818,9 @@ static bool conv_split_launch(hipStream_t st, ConvBatch &B) {
 // tile 16 x 8 x 16 outputs, 8 per thread; CH = rows of sy per staging pass, the most the 160 KB of LDS hold
 bool launch_conv_multi(hipStream_t st, ConvBatch &B) {
     if (B.n < 1) return false;
-    if (B.split > 1 || (B.split && B.c[0].nz < B.c[0].M[2])) { // a slab of planes (or on request)
+    bool cubes = false; // (stencils that come as several cubes stay with k_conv_multi, which the tests exercise with them)
+    for (int l = 0; l < B.n; l++) cubes = cubes || B.c[l].nsub != 1;
+    if (!cubes && (B.split > 1 || (B.split && B.c[0].nz < B.c[0].M[2]))) { // a slab of planes (or on request)
         if (B.c[0].ks[2] == 15 && conv_split_launch<15, 4, 5>(st, B)) return true;
         if (B.c[0].ks[2] == 13 && conv_split_launch<13, 4, 5>(st, B)) return true;
     }
