@@ -329,7 +329,14 @@ template <int P>
 __global__ __launch_bounds__(512) void k_interp_tiles(TileSrc S, SplineParams sp, TileGeom tl, const double *__restrict__ e,
                                                       double *__restrict__ acc, int remap) {
     constexpr int R = AT + P - 1, R3 = R * R * R;
-    __shared__ double blk[R3];
+    // Pitches of the block in LDS.  A read instruction takes, for every lane, the same node offset from the lane's own
+    // base (z cell, y cell, x cell of its particle); the particles of a wave sit in one or two columns of 2 x 2 cells,
+    // over the 8 z cells of the tile.  With a row pitch of 14 doubles and a plane pitch of 4 mod 32 the bases
+    // {0, 1} + 14 {0, 1} + 4 {0..7} (mod 32 doubles = the 64 banks) are all different: lanes of one column never
+    // collide, where the dense pitches 13 and 169 left 40 % of the LDS cycles to bank conflicts.
+    constexpr int P1 = 14, P2 = ((R * P1 - 4 + 31) / 32) * 32 + 4;
+    static_assert(P1 >= R && P2 >= R * P1, "pitches");
+    __shared__ double blk[R * P2];
     __shared__ int rowstart[AT * AT + 1], rowbase[AT * AT];
     // Whole grid: an XCD gets a contiguous run of tiles, whose blocks of potentials overlap.  A rank that owns a slab
     // has its particles in a contiguous run of tiles: those are dealt out over the XCDs one by one instead.
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(512) void k_interp_tiles(TileSrc S, SplineParams sp
     for (int t = threadIdx.x; t < R3; t += blockDim.x) {
         const int lx = t % R, ly = (t / R) % R, lz = t / (R * R);
         const int gx = modp(x0 - (P / 2 - 1) + lx, Mx), gy = modp(y0 - (P / 2 - 1) + ly, My), gz = modp(z0 - (P / 2 - 1) + lz, Mz);
-        blk[t] = e[((size_t)gz * My + gy) * Mx + gx];
+        blk[lz * P2 + ly * P1 + lx] = e[((size_t)gz * My + gy) * Mx + gx];
     }
     __syncthreads();
     for (int idx = blockIdx.y * share + threadIdx.x; idx < idx_end; idx += blockDim.x) {
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(512) void k_interp_tiles(TileSrc S, SplineParams sp
                 dw[d][P - 1 - v] = -piece_eval<P - 1>(sp.dpiece[v], g);
             }
         }
-        const double *__restrict__ b0 = blk + (rz * R + ry) * R + (cellx - x0);
+        const double *__restrict__ b0 = blk + rz * P2 + ry * P1 + (cellx - x0);
         double gx = 0, gy = 0, gz = 0;
 #pragma unroll 1
         for (int c = 0; c < P; c++) {
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(512) void k_interp_tiles(TileSrc S, SplineParams sp
             double px = 0, py = 0, pv = 0; // plane sums: d/dx, d/dy, value
 #pragma unroll
             for (int b = 0; b < P; b++) {
-                const double *row = b0 + (c * R + b) * R;
+                const double *row = b0 + c * P2 + b * P1;
                 double sv = 0, sd = 0; // sum_a w_a e, sum_a dw_a e along x
 #pragma unroll
                 for (int a = 0; a < P; a++) {
