@@ -1822,7 +1822,6 @@ bool launch_conv_multi(hipStream_t st, ConvBatch &B) {
     for (int l = 0; l < B.n; l++) cubes = cubes || B.c[l].nsub != 1;
     if (!cubes && (B.split > 1 || (B.split && B.c[0].nz < B.c[0].M[2]))) { // a slab of planes (or on request)
         if (B.c[0].ks[2] == 15 && conv_split_launch<15, 4, 5>(st, B)) return true;
-        if (B.c[0].ks[2] == 13 && conv_split_launch<13, 4, 5>(st, B)) return true;
     }
     switch (B.c[0].ks[2]) {
     case 7: return conv_multi_launch<7, 8, 16, 8, 16, 7>(st, B);
