@@ -90,6 +90,7 @@ struct msm_amd_handle {
     hipStream_t stream_g = nullptr; // coarse-level branch of the grid stage
     hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr;
     hipEvent_t pairs_after = nullptr; // set for one msm_amd_stage_pairs call: recorded between the list build and the pair kernel
+    int opt_conv_sym = 2;       // tiled convolution: mirror columns of a stencil share their multiplications (2: and 16 outputs per thread; 0: off)
     int opt_transfer_chain = 1; // two prolongations per launch where the grids allow it
     int opt_conv_groups = 1;  // slab ranks: the level-0 convolution by k_conv_split
     int opt_grid_streams = 0; // measured: slower (1.68 vs 1.65 ms at 1M; the chain of small kernels does not get CUs while the
@@ -531,6 +532,7 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "conv_small")) { h->opt_conv_small = value; return MSM_AMD_OK; }
     if (!strcmp(key, "anterp_tiled")) { h->opt_anterp_tiled = value; return MSM_AMD_OK; }
     if (!strcmp(key, "interp_threads")) { if (value >= 64 && value <= 512 && value % 64 == 0) { h->sopt.interp_threads = value; return MSM_AMD_OK; } }
+    if (!strcmp(key, "conv_sym")) { h->opt_conv_sym = value; return MSM_AMD_OK; }
     if (!strcmp(key, "transfer_chain")) { h->opt_transfer_chain = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "conv_groups")) { h->opt_conv_groups = value; return MSM_AMD_OK; } // 2: for whole grids too (A/B)
     if (!strcmp(key, "interp_remap")) { h->sopt.interp_remap = value != 0; return MSM_AMD_OK; }
@@ -738,6 +740,7 @@ static void convolve_ranges(msm_amd_handle *h, const std::vector<PlaneRange> &ra
         ConvBatch B;
         B.n = 0;
         B.split = h->opt_conv_groups;
+        B.sym = h->opt_conv_sym;
         std::vector<size_t> members;
         // A slab rank convolves a few planes of level 0: fewer tiles (16 x 8 x 16 outputs each) than the chip has CUs,
         // so the kernel lasts as long as one workgroup needs for all taps of its tile.  The taps are then shared out

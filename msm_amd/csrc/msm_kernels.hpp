@@ -169,6 +169,7 @@ struct ConvArgs {
 struct ConvBatch {
     int n;
     int split = 0;       // a slab of planes on level 0: tiles of 8 planes whose stencil columns are shared out over wave groups
+    int sym = 0;         // in: the caller allows the mirror symmetry of the stencils along x to be used (sums in another order)
     int blk0[9];
     int ntx[8], nty[8];
     ConvArgs c[8];
