@@ -1782,7 +1782,7 @@ static bool conv_multi_launch(hipStream_t st, ConvBatch &B) {
 // LDS at the end and are added in the order of the groups.  Four waves per SIMD hide what k_conv_multi hides by
 // prefetching, so the loop is the plain one.
 
-template <int SZ, int G, int CH>
+template <int SZ, int G, int CH, bool SYM = false>
 __global__ __launch_bounds__(128 * G, 4) void k_conv_split(ConvBatch B) {
     constexpr int R = 8, TX = 16, TY = 8, TZ = 8;
     extern __shared__ double lds[];
@@ -1845,6 +1845,35 @@ __global__ __launch_bounds__(128 * G, 4) void k_conv_split(ConvBatch B) {
             }
             __syncthreads();
             const double *colc = lds + (tx + SZ - 1) * LY + (ty + c0 + nch - 1);
+            if (SYM) {
+                // mirror columns j and SZ - 1 - j of a centred stencil together (see k_conv_multi): SZ / 2 pairs and the
+                // middle column, shared out over the groups
+                constexpr int NP = SZ / 2, SPG = (NP + 1 + G - 1) / G;
+                for (int sy = c0; sy < c0 + nch; sy++) {
+#pragma unroll
+                    for (int s = 0; s < SPG; s++) {
+                        const int j = grp * SPG + s;
+                        if (j <= NP) {
+                            const double *ca = colc - (j * LY + sy), *cb = colc - ((SZ - 1 - j) * LY + sy);
+                            const ctap_t *kk = Kt + (size_t)(sy * SZ + j) * SZ;
+                            double sm[W], kc[SZ];
+#pragma unroll
+                            for (int w = 0; w < W; w++) sm[w] = ca[w * plane];
+                            if (j < NP) {
+#pragma unroll
+                                for (int w = 0; w < W; w++) sm[w] += cb[w * plane];
+                            }
+#pragma unroll
+                            for (int z = 0; z < SZ; z++) kc[z] = kk[z];
+#pragma unroll
+                            for (int z = 0; z < SZ; z++)
+#pragma unroll
+                                for (int r = 0; r < R; r++) acc[r] = fma(kc[z], sm[r + SZ - 1 - z], acc[r]);
+                        }
+                    }
+                }
+                continue;
+            }
             for (int sy = c0; sy < c0 + nch; sy++) {
 #pragma unroll
                 for (int s = 0; s < SXG; s++) {
@@ -1886,7 +1915,7 @@ __global__ __launch_bounds__(128 * G, 4) void k_conv_split(ConvBatch B) {
     }
 }
 
-template <int SZ, int G, int CH>
+template <int SZ, int G, int CH, bool SYM = false>
 static bool conv_split_launch(hipStream_t st, ConvBatch &B) {
     constexpr int TX = 16, TY = 8, TZ = 8, CHR = CH < SZ ? CH : SZ;
     constexpr int LX = TX + SZ - 1, LY = ((TY + CHR - 1 + 1) / 4) * 4 + 2, LZ = TZ + SZ - 1;
@@ -1904,7 +1933,7 @@ static bool conv_split_launch(hipStream_t st, ConvBatch &B) {
     }
     B.blk0[B.n] = nblk;
     if (nblk == 0) return false;
-    auto kern = k_conv_split<SZ, G, CH>;
+    auto kern = k_conv_split<SZ, G, CH, SYM>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
@@ -1927,6 +1956,7 @@ bool launch_conv_multi(hipStream_t st, ConvBatch &B) {
     for (int l = 0; l < B.n; l++) centred = centred && (B.c[l].ks[0] & 1) && B.c[l].kf[0] == -(B.c[l].ks[0] / 2);
     if (!centred) B.sym = 0;
     if (!cubes && (B.split > 1 || (B.split && B.c[0].nz < B.c[0].M[2]))) { // a slab of planes (or on request)
+        if (B.c[0].ks[2] == 15 && B.sym && conv_split_launch<15, 4, 5, true>(st, B)) return true;
         if (B.c[0].ks[2] == 15 && conv_split_launch<15, 4, 5>(st, B)) return true;
     }
     switch (B.c[0].ks[2]) {
