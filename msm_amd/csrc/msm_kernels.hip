@@ -1972,7 +1972,9 @@ bool launch_conv_multi(hipStream_t st, ConvBatch &B) {
         if (B.sym) return conv_multi_launch<15, 8, 16, 8, 16, 3, true>(st, B);
         return conv_multi_launch<15, 8, 16, 8, 16, 3>(st, B); // 30 x 10 x 30: two workgroups per CU (2 % faster than the whole halo at once)
     case 17: return conv_multi_launch<17, 8, 16, 8, 16, 11>(st, B); // 32 x 18 x 32 doubles
-    case 19: return conv_multi_launch<19, 8, 16, 8, 16, 7>(st, B);  // 34 x 14 x 34
+    case 19:
+        if (B.sym == 2) return conv_multi_launch<19, 16, 16, 8, 32, 3, true>(st, B); // 34 x 10 x 50
+        return conv_multi_launch<19, 8, 16, 8, 16, 7>(st, B);  // 34 x 14 x 34
     case 21: return conv_multi_launch<21, 8, 16, 8, 16, 7>(st, B);  // 36 x 14 x 36
     case 23: return conv_multi_launch<23, 8, 16, 8, 16, 7>(st, B);  // 38 x 14 x 38
     default:

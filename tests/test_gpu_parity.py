@@ -299,7 +299,7 @@ def test_anterpolation_tiled(msm, torch, p, M):
     sp.close()
 
 
-@pytest.mark.parametrize("abar,p", [(4.5, 4), (5.0, 6), (5.5, 4), (6.0, 4)])
+@pytest.mark.parametrize("abar,p", [(3.61, 4), (4.03, 6), (4.5, 4), (5.0, 6), (5.5, 4), (6.0, 4)])   # 17, 19, 21, 23, 25, 29 taps
 def test_wide_stencils(msm, torch, abar, p):
     """Stencils wider than the LDS tile's full halo (17..23 taps per axis) are applied in several staging
     passes by the multi-level convolution kernel: grids and totals against the oracle."""
