@@ -103,7 +103,11 @@ struct msm_amd_handle {
                               // slower at 2, 3 and 4 workgroups per CU, and kernels of a second stream gain nothing from the room)
     int opt_slab_overlap = 1; // slab step: the charge exchange on a second stream beside the pair sum (0: one stream, for several
                               // processes sharing one GPU, where cross-stream waits were seen to stall)
-    int opt_overlap = 0; // measured: +5 % evaluations/s, but the pair kernel's workgroups starve the large convolution blocks
+    // parts of the grid branch on a second stream beside the pair branch: 1 all of it (slower: the level-0 convolution
+    // wants the FP64 pipe the pair kernel is using), 2 the anterpolation (bound by the LDS port: -22 us), 3 and the chain
+    // of the coarser levels (-35 us), 4 as 3, from the end of the list build on.  0: the stage times and the pair
+    // kernel's own duration stay those of kernels that have the chip to themselves.
+    int opt_overlap = 0;
     int opt_transfer_fused = 4;              // 4: restriction and prolongation tiled through LDS, one launch per level (default); 3: restriction
                                              // only; 0: separable passes; 1, 2: thread per node, slower at every size measured
     long opt_transfer_fused_max = 1L << 30;

@@ -267,7 +267,7 @@ class SlabRank:
         if perturb:
             self._make_position_sets()
         self._pending = self._pending_work = self._energies = None
-        # The real engine runs the whole step in C (msm_amd_slab_step: pair sum beside the grid branch on two streams,
+        # The real engine runs the whole step in C (msm_amd_slab_step: the exchange on a second stream beside the pair sum,
         # collectives from a table); a stand-in engine (CPU tests of the partition logic) is driven stage by stage below.
         self.mode = mode
         self.coll = None
