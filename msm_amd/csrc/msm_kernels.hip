@@ -1541,6 +1541,8 @@ __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
     constexpr int W = R + SZ - 1;
     constexpr int plane = LX * LY;
     const int half = threadIdx.x >> 5, hl = threadIdx.x & 31;
+    int txm = tx;
+    if (SYM) asm volatile("" : "+v"(txm));
     double acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.0;
@@ -1646,8 +1648,13 @@ __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
         if (SYM) {
             constexpr int NP = SZ / 2; // steps 0 .. NP - 1: columns j and SZ - 1 - j together; step NP: the middle column
             double va[W], vb[W], kc[SZ];
+            // The mirror column is addressed from a base of its own (txm is tx behind an empty asm).  The two columns
+            // of a step are an even number of doubles apart; read by one two-address instruction, which is what the
+            // compiler makes of a constant distance, 16 lanes x 2 addresses are served together and fall on the same 16
+            // of the 32 bank pairs (counters: 2-way conflicts on every such read, 45 % of the LDS cycles).
+            const double *colm = lds + (tg * R) * plane + (txm + SZ - 1) * LY + (ty + c0 + nch - 1);
             {
-                const double *ca = colc - c0, *cb = colc - ((SZ - 1) * LY + c0);
+                const double *ca = colc - c0, *cb = colm - ((SZ - 1) * LY + c0);
                 const ctap_t *kk = Kt + (size_t)c0 * SZ * SZ;
 #pragma unroll
                 for (int w = 0; w < W; w++) { va[w] = ca[w * plane]; vb[w] = cb[w * plane]; }
@@ -1670,7 +1677,7 @@ __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
                         const int nsy = last ? (more ? sy + 1 : sy) : sy;
                         constexpr int dummy = 0;
                         const int nj = last ? dummy : j + 1;
-                        const double *ca = colc - (nj * LY + nsy), *cb = colc - ((SZ - 1 - nj) * LY + nsy);
+                        const double *ca = colc - (nj * LY + nsy), *cb = colm - ((SZ - 1 - nj) * LY + nsy);
                         const ctap_t *kk = Kt + (size_t)(nsy * SZ + nj) * SZ;
 #pragma unroll
                         for (int w = 0; w < W; w++) va[w] = ca[w * plane];

@@ -369,10 +369,20 @@ __global__ __launch_bounds__(512) void k_interp_tiles(TileSrc S, SplineParams sp
     // the tile's particles may be shared between gridDim.y workgroups (a rank that owns a thin slab has few tiles)
     const int share = (total + gridDim.y - 1) / gridDim.y, idx_end = min(total, ((int)blockIdx.y + 1) * share);
     if ((int)blockIdx.y * share >= total) return;
-    for (int t = threadIdx.x; t < R3; t += blockDim.x) {
-        const int lx = t % R, ly = (t / R) % R, lz = t / (R * R);
-        const int gx = modp(x0 - (P / 2 - 1) + lx, Mx), gy = modp(y0 - (P / 2 - 1) + ly, My), gz = modp(z0 - (P / 2 - 1) + lz, Mz);
-        blk[lz * P2 + ly * P1 + lx] = e[((size_t)gz * My + gy) * Mx + gx];
+    // staged four loads at a time per thread: one trip to L2 per batch instead of one per node
+    for (int t0 = threadIdx.x; t0 < R3; t0 += 4 * blockDim.x) {
+        double v[4];
+        int at[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int t = min(t0 + k * (int)blockDim.x, R3 - 1);
+            const int lx = t % R, ly = (t / R) % R, lz = t / (R * R);
+            const int gx = modp(x0 - (P / 2 - 1) + lx, Mx), gy = modp(y0 - (P / 2 - 1) + ly, My), gz = modp(z0 - (P / 2 - 1) + lz, Mz);
+            at[k] = lz * P2 + ly * P1 + lx;
+            v[k] = e[((size_t)gz * My + gy) * Mx + gx];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) blk[at[k]] = v[k]; // a clamped index stores the last node's value again
     }
     __syncthreads();
     for (int idx = blockIdx.y * share + threadIdx.x; idx < idx_end; idx += blockDim.x) {
@@ -383,8 +393,8 @@ __global__ __launch_bounds__(512) void k_interp_tiles(TileSrc S, SplineParams sp
         }
         const int s = rowbase[lo] + (idx - rowstart[lo]);
         const int orig = S.order[s];
+        const double4 pt = S.ps[s]; // asked for together with the index (padding slots hold a far-away particle)
         if (orig >= sp.n_owned) continue;
-        const double4 pt = S.ps[s];
         const double ux = pt.x * S.scale[0], uy = pt.y * S.scale[1], uz = pt.z * S.scale[2];
         const int cellx = tile_cell(ux, x0, nxc), ry = tile_cell(uy, y0, nyc) - y0, rz = tile_cell(uz, z0, nzc) - z0;
         const double f[3] = {ux - (double)cellx, uy - (double)(y0 + ry), uz - (double)(z0 + rz)};
