@@ -11,6 +11,12 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 F = os.path.join(ROOT, "gpurun_out", "final") + os.sep
 P = os.path.join(ROOT, "profiles", tag + "_")
 KERNEL = "k_pair_clusters_filtered"
+# gpurun merges every capture into the same directories: keep the files of the newest run (one process id prefix) only
+for sub in ("stats", "fetch", "write", "sq", "fetch4", "write4"):
+    infos = sorted(glob.glob(F + sub + "/**/*_agent_info.csv", recursive=True), key=os.path.getmtime)
+    for old in infos[:-1]:
+        for f in glob.glob(old[:-len("agent_info.csv")] + "*"):
+            os.remove(f)
 shutil.copy(F + "bench_default.json", P + "bench_default.json")
 shutil.copy(F + "bench_order4.json", P + "bench_order4.json")
 shutil.copy(glob.glob(F + "stats/**/*kernel_stats.csv", recursive=True)[0], P + "bench_default_kernel_stats.csv")
