@@ -1802,7 +1802,7 @@ __global__ __launch_bounds__(128 * G, 4) void k_conv_split(ConvBatch B) {
     const int Mx = c.M[0], My = c.M[1], Mz = c.M[2];
     constexpr int CHR = CH < SZ ? CH : SZ;
     constexpr int LX = TX + SZ - 1, LY = ((TY + CHR - 1 + 1) / 4) * 4 + 2, LZ = TZ + SZ - 1;
-    static_assert(LX <= 32, "a row is staged by half a wave");
+    static_assert(LX <= 64, "a row is staged by half a wave in at most two steps");
     const int bid = blockIdx.x - B.blk0[lev];
     const int bx = bid % ntx, by = (bid / ntx) % nty, bz = bid / (ntx * nty);
     const int X0 = bx * TX, Y0 = by * TY, Z0 = c.z0 + bz * TZ;
@@ -1823,7 +1823,7 @@ __global__ __launch_bounds__(128 * G, 4) void k_conv_split(ConvBatch B) {
         const int ca = cube % c.nsub, cb = (cube / c.nsub) % c.nsub, cc = cube / (c.nsub * c.nsub);
         const int ox = X0 - (c.kf[0] + ca * SZ + SZ - 1), oy = Y0 - (c.kf[1] + cb * SZ + SZ - 1), oz = Z0 - (c.kf[2] + cc * SZ + SZ - 1);
         const ctap_t *Kt = (const ctap_t *)(B.Kt[lev] + (size_t)cube * (SZ * SZ * SZ));
-        const int gx0 = modp(ox + hl, Mx);
+        const int gx0 = modp(ox + hl, Mx), gx1 = modp(ox + hl + 32, Mx);
         for (int c0 = sy_lo; c0 < sy_hi; c0 += CHR) {
             const int nch = min(CHR, sy_hi - c0);
             const int ys = SZ - c0 - nch;
@@ -1838,15 +1838,18 @@ __global__ __launch_bounds__(128 * G, 4) void k_conv_split(ConvBatch B) {
                     double *lrow = lds + lz * plane + hl * LY;
                     int yw = yw0;
                     for (int b = 0; b < rows; b += BATCH) {
-                        double v0[BATCH];
+                        double v0[BATCH], v1[LX > 32 ? BATCH : 1];
 #pragma unroll
                         for (int k = 0; k < BATCH; k++) {
                             if (b + k < rows && hl < LX) v0[k] = pl[(size_t)yw * Mx + gx0];
+                            if (LX > 32 && b + k < rows && hl + 32 < LX) v1[LX > 32 ? k : 0] = pl[(size_t)yw * Mx + gx1];
                             yw = yw + 1 == My ? 0 : yw + 1;
                         }
 #pragma unroll
-                        for (int k = 0; k < BATCH; k++)
+                        for (int k = 0; k < BATCH; k++) {
                             if (b + k < rows && hl < LX) lrow[b + k] = v0[k];
+                            if (LX > 32 && b + k < rows && hl + 32 < LX) lrow[32 * LY + b + k] = v1[LX > 32 ? k : 0];
+                        }
                     }
                 }
             }
@@ -1965,6 +1968,8 @@ bool launch_conv_multi(hipStream_t st, ConvBatch &B) {
     if (!cubes && (B.split > 1 || (B.split && B.c[0].nz < B.c[0].M[2]))) { // a slab of planes (or on request)
         if (B.c[0].ks[2] == 15 && B.sym && conv_split_launch<15, 4, 5, true>(st, B)) return true;
         if (B.c[0].ks[2] == 15 && conv_split_launch<15, 4, 5>(st, B)) return true;
+        if (B.c[0].ks[2] == 19 && B.sym && conv_split_launch<19, 4, 3, true>(st, B)) return true;
+        if (B.c[0].ks[2] == 19 && conv_split_launch<19, 4, 3>(st, B)) return true;
     }
     switch (B.c[0].ks[2]) {
     case 7: return conv_multi_launch<7, 8, 16, 8, 16, 7>(st, B);

@@ -59,6 +59,7 @@ struct SplineParams {
 struct TileGeom {
     int nt[3];
     int ntiles;
+    int tz0 = 0; // first layer of tiles along z that a launch covers: workgroup b takes tile b of the layers tz0, tz0 + 1, ... (wrapping)
 };
 
 // ---- binning ----

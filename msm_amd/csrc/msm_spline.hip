@@ -63,6 +63,13 @@ __device__ __forceinline__ void lds_add(double *p, double v) {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
+// tile of a workgroup when a launch covers some layers of tiles only (TileGeom::tz0)
+__device__ __forceinline__ int launched_tile(const TileGeom &tl, int b) {
+    const int per = tl.nt[0] * tl.nt[1];
+    const int layer = b / per;
+    return ((tl.tz0 + layer) % tl.nt[2]) * per + (b - layer * per);
+}
+
 template <int P>
 __global__ __launch_bounds__(256) void k_anterp_tiles(TileSrc S, SplineParams sp, TileGeom tl, double *__restrict__ scratch,
                                                       int *__restrict__ tile_used) {
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(256) void k_anterp_tiles(TileSrc S, SplineParams sp
     __shared__ int any_particle;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     double *__restrict__ mine = lds + wave * R3;
-    const int tile = blockIdx.x;
+    const int tile = launched_tile(tl, blockIdx.x);
     const int tx = tile % tl.nt[0], ty = (tile / tl.nt[0]) % tl.nt[1], tz = tile / (tl.nt[0] * tl.nt[1]);
     const int Mx = sp.M[0], My = sp.M[1], Mz = sp.M[2];
     const int x0 = tx * AT, y0 = ty * AT, z0 = tz * AT;
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(1024) void k_anterp_cols(TileSrc S, SplineParams sp
     __shared__ int sbnd[MAXRUNS][AT + 1]; // per run: the slots at which the z cells of the tile begin
     __shared__ int any_particle;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int tile = blockIdx.x;
+    const int tile = launched_tile(tl, blockIdx.x);
     const int tx = tile % tl.nt[0], ty = (tile / tl.nt[0]) % tl.nt[1], tz = tile / (tl.nt[0] * tl.nt[1]);
     const int x0 = tx * AT, y0 = ty * AT, z0 = tz * AT;
     const int nxc = min(AT, sp.M[0] - x0), nyc = min(AT, sp.M[1] - y0), nzc = min(AT, sp.M[2] - z0);
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(512) void k_interp_tiles(TileSrc S, SplineParams sp
     __shared__ int rowstart[AT * AT + 1], rowbase[AT * AT];
     // Whole grid: an XCD gets a contiguous run of tiles, whose blocks of potentials overlap.  A rank that owns a slab
     // has its particles in a contiguous run of tiles: those are dealt out over the XCDs one by one instead.
-    const int tile = remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int tile = launched_tile(tl, remap ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x);
     const int tx = tile % tl.nt[0], ty = (tile / tl.nt[0]) % tl.nt[1], tz = tile / (tl.nt[0] * tl.nt[1]);
     const int Mx = sp.M[0], My = sp.M[1], Mz = sp.M[2];
     const int x0 = tx * AT, y0 = ty * AT, z0 = tz * AT;
@@ -448,19 +455,44 @@ __global__ __launch_bounds__(512) void k_interp_tiles(TileSrc S, SplineParams sp
     }
 }
 
-void launch_interp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, const double *egrid,
+// The layers of tiles a slab rank has to visit: those with a cell within `margin` cells of its planes [z0, z0 + nz).
+// (The other tiles hold halo copies that reach none of the rank's planes, or nothing: launched, their workgroups would only
+// find that out after a chain of index loads, which at 256^3 nodes is most of the kernel's time.)  A range that wraps
+// around a grid whose size is not a multiple of the tile edge keeps all layers.
+static TileGeom launched_layers(const TileGeom &tl, const SplineParams &sp, int margin, int &count) {
+    TileGeom t = tl;
+    t.tz0 = 0;
+    count = tl.ntiles;
+    if (sp.nz >= sp.M[2]) return t;
+    const int lo = sp.z0 - margin, hi = sp.z0 + sp.nz - 1 + margin;
+    if ((lo < 0 || hi >= sp.M[2]) && sp.M[2] % AT != 0) return t;
+    const int a = lo >= 0 ? lo / AT : -((-lo + AT - 1) / AT), b = hi / AT; // floor division
+    if (b - a + 1 >= tl.nt[2]) return t;
+    t.tz0 = ((a % tl.nt[2]) + tl.nt[2]) % tl.nt[2];
+    count = (b - a + 1) * tl.nt[0] * tl.nt[1];
+    return t;
+}
+
+void launch_interp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl_all, const double *egrid,
                          double *acc, const SplineOpts &opt) {
+    // owned particles only; one cell of margin for a particle whose cell and slab were rounded differently
+    int ntl;
+    const TileGeom tl = launched_layers(tl_all, sp, 1, ntl);
     const int ns = opt.interp_split ? opt.interp_split : 1;
     const bool slab = sp.nz < sp.M[2];
     // a slab rank has few busy tiles: more threads to each
     const int nthreads = slab ? std::max(512, opt.interp_threads) : opt.interp_threads;
     const int remap = !slab && opt.interp_remap;
-    if (sp.p == 4) hipLaunchKernelGGL((k_interp_tiles<4>), dim3(tl.ntiles, ns), dim3(nthreads), 0, st, S, sp, tl, egrid, acc, remap);
-    else hipLaunchKernelGGL((k_interp_tiles<6>), dim3(tl.ntiles, ns), dim3(nthreads), 0, st, S, sp, tl, egrid, acc, remap);
+    if (sp.p == 4) hipLaunchKernelGGL((k_interp_tiles<4>), dim3(ntl, ns), dim3(nthreads), 0, st, S, sp, tl, egrid, acc, remap);
+    else hipLaunchKernelGGL((k_interp_tiles<6>), dim3(ntl, ns), dim3(nthreads), 0, st, S, sp, tl, egrid, acc, remap);
 }
 
-bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, double *scratch,
+bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl_all, double *scratch,
                          int *tile_used, double *grid, const SplineOpts &opt) {
+    // a particle reaches p/2 planes below and above its cell (and one cell of margin as in the interpolation); the
+    // combine kernel reads the blocks of exactly these tiles
+    int ntl;
+    const TileGeom tl = launched_layers(tl_all, sp, sp.p / 2 + 1, ntl);
     const size_t n = (size_t)sp.M[0] * sp.M[1] * sp.nz;
     const int gb = (int)((n + 255) / 256);
     static bool attr4 = false, attr6 = false;
@@ -484,7 +516,7 @@ bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &s
             const int nw = opt.anterp_cols_waves ? opt.anterp_cols_waves : (2 * sp.nz <= sp.M[2] ? 8 : 4);
             const int rec = (2 + sp.p + 1 + 1) / 2 * 2;
             const size_t dyn = sizeof(double) * ((size_t)(R * R * R + 1) / 2 * 2 + (size_t)nw * 64 * rec);
-            hipLaunchKernelGGL(k, dim3(tl.ntiles), dim3(64 * nw), dyn, st, S, sp, tl, scratch, tile_used);
+            hipLaunchKernelGGL(k, dim3(ntl), dim3(64 * nw), dyn, st, S, sp, tl, scratch, tile_used);
             if (sp.p == 4) hipLaunchKernelGGL((k_anterp_combine<4>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
             else hipLaunchKernelGGL((k_anterp_combine<6>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
             return true;
@@ -499,7 +531,7 @@ bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &s
             return false;
         }
         attr4 = true;
-        hipLaunchKernelGGL(kern, dim3(tl.ntiles), dim3(256), bytes, st, S, sp, tl, scratch, tile_used);
+        hipLaunchKernelGGL(kern, dim3(ntl), dim3(256), bytes, st, S, sp, tl, scratch, tile_used);
         hipLaunchKernelGGL((k_anterp_combine<4>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
     } else {
         const size_t bytes = 4 * sizeof(double) * (AT + 5) * (AT + 5) * (AT + 5);
@@ -509,7 +541,7 @@ bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &s
             return false;
         }
         attr6 = true;
-        hipLaunchKernelGGL(kern, dim3(tl.ntiles), dim3(256), bytes, st, S, sp, tl, scratch, tile_used);
+        hipLaunchKernelGGL(kern, dim3(ntl), dim3(256), bytes, st, S, sp, tl, scratch, tile_used);
         hipLaunchKernelGGL((k_anterp_combine<6>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
     }
     return true;

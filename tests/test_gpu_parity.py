@@ -320,6 +320,34 @@ def test_wide_stencils(msm, torch, abar, p):
     sp.close()
 
 
+@pytest.mark.parametrize("a_over_h,p,taps", [(4.0, 6, 15), (4.0, 4, 15), (4.6, 6, 19)])
+def test_slab_convolution_kernel_on_whole_grids(msm, torch, a_over_h, p, taps):
+    """The convolution kernel of the slab ranks (tiles of 8 planes, the stencil columns shared out over four groups of
+    waves) applied to whole grids, with and without the mirror columns taken together: every level against the oracle."""
+    N, A, M, L = 20000, (1.0, 1.0, 1.0), (48, 48, 48), 2
+    r, q = O.neutral_system(N, A, seed=41)
+    lib = msm.load()
+    a = a_over_h / M[0]
+    hL = (2.0 ** (L - 1)) * A[0] / M[0]
+    beta = lib.choosebetaNew(1e-12, (2.0 ** L) * a, hL)
+    kmax = int(np.ceil(lib.choosekmax(1e-12, beta, hL)))
+    desc = msm.plan_explicit(N, A, M, p, 10, L, a, beta, kmax)
+    eng = msm.Engine(desc)
+    assert eng.stencil(0)[0].shape[0] == taps
+    sp = spec_for(desc)
+    ref = sp.eval(r, q)
+    for sym in (2, 0):
+        eng.set_option("conv_groups", 2)
+        eng.set_option("conv_sym", sym)
+        en, acc = eng.eval(r, q)
+        for l in range(desc.L):
+            assert grid_err(eng.grid(msm.capi.GRID_E, l), sp.grid("e", l)) < TOL, (l, sym)
+        assert np.abs(en - ref["energies"]).max() < TOL * np.abs(ref["energies"][:6]).max()
+        assert rel_rms(acc.cpu().numpy(), ref["acc"]) < TOL
+    eng.close()
+    sp.close()
+
+
 @pytest.mark.parametrize("a_over_h,p,width", [(6.3, 4, 25), (7.6, 6, 31), (8.8, 4, 35)])
 def test_very_wide_stencils(msm, torch, a_over_h, p, width):
     """Stencils beyond 23 taps per axis (a grid of half the usual spacing, or a long cutoff) are cut into cubes that

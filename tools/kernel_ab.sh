@@ -8,6 +8,6 @@ for o in "$@"; do
     d=$R/gpurun_out/kab/$(echo "$o" | tr ',=' '__')
     rm -rf "$d"; mkdir -p "$d"
     timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$d" -- python3 $R/tools/rank_sim.py $W 6 "$o" > "$d/log.txt" 2>&1 || exit 1
-    grep "^W 8\|^W 4\|^W 2\|^W 1" "$d/log.txt" | sed "s/^/$o /"
+    grep "^N " "$d/log.txt" | sed "s/^/$o /"
     grep -E "$PAT" "$d"/*/*kernel_stats.csv | awk -F'","|",|,"' -v o="$o" '{n=$1; sub(/.*"/,"",n); printf "   %s  %-60.60s calls %s avg_ns %s\n", o, n, $2, $4}'
 done

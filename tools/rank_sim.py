@@ -14,7 +14,7 @@ class FakeDist:
     def all_gather_into_tensor(self, out, inp, async_op=False): return FakeWork()
     def all_reduce(self, t, async_op=False): return None
 
-N = 1000000; p = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+N = int(os.environ.get("RANK_SIM_N", "1000000")); p = int(sys.argv[2]) if len(sys.argv) > 2 else 6   # RANK_SIM_N: particles of the whole system
 W = int(sys.argv[1])
 r, q = make_system(N, 20261113)
 desc = msm_amd.plan_auto(N, (1.0, 1.0, 1.0), p, 10, 4.0, 0)
@@ -33,4 +33,4 @@ for _ in range(20): s.step(want_energies=False)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 20
 prof = SlabProfiler(torch, s).profile(5)
-print("W", W, "p", p, "mode", s.eng.slab_exchange_mode(W, mode) if W > 1 else "-", "c_step", s.coll is not None, "n_own", s.n_own, "n_tot", s.n_tot, "ms/step", round(dt * 1e3, 3), {k: round(v, 3) for k, v in prof.items()})
+print("N", N, "M", list(desc.M), "W", W, "p", p, "mode", s.eng.slab_exchange_mode(W, mode) if W > 1 else "-", "c_step", s.coll is not None, "n_own", s.n_own, "n_tot", s.n_tot, "ms/step", round(dt * 1e3, 3), {k: round(v, 3) for k, v in prof.items()})
