@@ -93,6 +93,7 @@ struct msm_amd_handle {
     int opt_conv_sym = 2;       // tiled convolution: mirror columns of a stencil share their multiplications (2: and 16 outputs per thread; 0: off)
     int opt_transfer_chain = 1; // two prolongations per launch where the grids allow it
     int opt_conv_groups = 1;  // slab ranks: the level-0 convolution by k_conv_split
+    int opt_slab_level1 = 1;  // slab ranks: level 1 convolved on the planes under the rank's own only
     int opt_grid_streams = 0; // measured: slower (1.68 vs 1.65 ms at 1M; the chain of small kernels does not get CUs while the
                               // level-0 convolution runs), and cross-stream waits stalled with 4 processes sharing one GPU
     hipEvent_t ev_fork = nullptr, ev_pairs = nullptr, ev_join = nullptr;
@@ -538,6 +539,7 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "interp_threads")) { if (value >= 64 && value <= 512 && value % 64 == 0) { h->sopt.interp_threads = value; return MSM_AMD_OK; } }
     if (!strcmp(key, "conv_sym")) { h->opt_conv_sym = value; return MSM_AMD_OK; }
     if (!strcmp(key, "transfer_chain")) { h->opt_transfer_chain = value != 0; return MSM_AMD_OK; }
+    if (!strcmp(key, "slab_level1")) { h->opt_slab_level1 = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "conv_groups")) { h->opt_conv_groups = value; return MSM_AMD_OK; } // 2: for whole grids too (A/B)
     if (!strcmp(key, "interp_remap")) { h->sopt.interp_remap = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "interp_split")) { if (value >= 0 && value <= 16) { h->sopt.interp_split = value; return MSM_AMD_OK; } }
@@ -882,8 +884,27 @@ static int grid_stage(msm_amd_handle *h, bool front_done, int part = 0) {
     }
     // the coarsest level's convolution belongs to top_level() when it is fused with the Fourier level or open
     const bool fused_top = top_fused(h) || d.open_boundary;
-    for (int l = 1; l < L; l++)
-        if (!(fused_top && l == L - 1)) coarse.push_back({l, 0, h->hp.Ml[l][2]});
+    for (int l = 1; l < L; l++) {
+        if (fused_top && l == L - 1) continue;
+        const int M1 = h->hp.Ml[l][2];
+        if (slab && l == 1 && h->opt_slab_level1) {
+            // Level 1 of a slab rank: its potentials are read by the last prolongation only, for the fine planes
+            // [z0 - p/2, z0 + nz + p/2), i.e. on the coarse planes below them and p/2 either side (one more for the
+            // rounding of the halves).  The charges of level 1 are complete on every rank, so the rank convolves these
+            // planes by itself; the other planes of ge[1] keep whatever they held (the prolongation from level 2 is
+            // added to them as well, nothing reads them).  At 256^3 nodes and 8 ranks that is 26 planes of 128.
+            const int flo = d.zplane0 - p / 2, fhi = d.zplane0 + d.nzplanes + p / 2 - 1;
+            const int clo = (flo >= 0 ? flo / 2 : -((1 - flo) / 2)) - p / 2 - 1, chi = (fhi >= 0 ? fhi / 2 : -((1 - fhi) / 2)) + p / 2 + 1;
+            const int n = chi - clo + 1;
+            if (n < M1) {
+                const int lo = ((clo % M1) + M1) % M1, first = std::min(n, M1 - lo);
+                coarse.push_back({l, lo, first});
+                if (n > first) coarse.push_back({l, 0, n - first});
+                continue;
+            }
+        }
+        coarse.push_back({l, 0, M1});
+    }
     if (fused_top && L == 1) fine.clear();
 
     // Two branches that only meet at the last prolongation: the level-0 convolution (most of the arithmetic, fills the
