@@ -68,6 +68,9 @@ SLAB_CASES = [
     # the benchmark's grid split eight ways: 12 planes per rank, cutoff above half a slab (halo particles outnumber the
     # owned ones), 16 halo planes would not fit the neighbour's slab: all-gather
     (8, ("explicit", 60000, 6, 4, 96, 0.07), 0, True, 1),
+    # a grid that is no multiple of the 8-cell tiles of the spline kernels, three ranks: the middle one visits some layers
+    # of tiles only, the outer ones (their halo wraps around the odd last layer) all of them
+    (3, ("explicit", 50000, 6, 3, 60, 0.05), 0, True, 2),
 ]
 
 
