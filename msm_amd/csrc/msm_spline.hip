@@ -319,12 +319,33 @@ __global__ __launch_bounds__(256) void k_anterp_combine(const double *__restrict
     int tix[3], lix[3], tiy[3], liy[3], tiz[3], liz[3];
     const int nx = axis_sources<P>(jx, Mx, tix, lix), ny = axis_sources<P>(jy, My, tiy, liy), nz = axis_sources<P>(jz, sp.M[2], tiz, liz);
     double sum = 0.0;
-    for (int kz = 0; kz < nz; kz++)
-        for (int ky = 0; ky < ny; ky++)
-            for (int kx = 0; kx < nx; kx++) {
-                const size_t t = ((size_t)tiz[kz] * tl.nt[1] + tiy[ky]) * tl.nt[0] + tix[kx];
-                if (tile_used[t]) sum += scratch[t * R3 + (liz[kz] * R + liy[ky]) * R + lix[kx]];
-            }
+    if (nx <= 2 && ny <= 2 && nz <= 2) {
+        // the usual case, at most two blocks per axis: the flags of the (up to) eight tiles are requested together and
+        // then their values, two round trips to L2 instead of up to sixteen; same terms, same order
+        size_t at[8];
+        int used[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int kx = k & 1, ky = (k >> 1) & 1, kz = k >> 2;
+            const bool have = kx < nx && ky < ny && kz < nz;
+            const size_t t = ((size_t)tiz[kz < nz ? kz : 0] * tl.nt[1] + tiy[ky < ny ? ky : 0]) * tl.nt[0] + tix[kx < nx ? kx : 0];
+            at[k] = t * R3 + (liz[kz < nz ? kz : 0] * R + liy[ky < ny ? ky : 0]) * R + lix[kx < nx ? kx : 0];
+            used[k] = have ? tile_used[t] : 0;
+        }
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = used[k] ? scratch[at[k]] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (used[k]) sum += v[k];
+    } else {
+        for (int kz = 0; kz < nz; kz++)
+            for (int ky = 0; ky < ny; ky++)
+                for (int kx = 0; kx < nx; kx++) {
+                    const size_t t = ((size_t)tiz[kz] * tl.nt[1] + tiy[ky]) * tl.nt[0] + tix[kx];
+                    if (tile_used[t]) sum += scratch[t * R3 + (liz[kz] * R + liy[ky]) * R + lix[kx]];
+                }
+    }
     grid[((size_t)jz * My + jy) * Mx + jx] = sum;
 }
 
