@@ -376,6 +376,11 @@ int msm_amd_last_timings(msm_amd_handle *h, double ms[10]);
  * of HIP events: "pair_kernel" (the cluster-pair kernel alone, without the sort and the list build that the
  * "pairs" stage above includes).  MSM_AMD_EINVAL for an unknown name or when that kernel did not run. */
 int msm_amd_last_kernel_ms(msm_amd_handle *h, const char *name, double *ms);
+/* Profiling hook with no counterpart in the reference: d_buffer is device memory of 4 x 64-bit words per cluster slot
+ * (msm_amd_pair_trace_slots() slots) which the list-walking pair kernel fills, per wave, with {start, end (100 MHz
+ * clock), hardware id | XCD id << 32, kind (1 empty slot, 2 halo copies only, 3 evaluated)}; NULL switches it off. */
+int msm_amd_set_pair_trace(msm_amd_handle *h, void *d_buffer);
+long msm_amd_pair_trace_slots(msm_amd_handle *h);
 /* enable per-stage event timing (adds event records to the stream); off by default */
 void msm_amd_set_profiling(msm_amd_handle *h, int on);
 /* select kernel variants (for A/B benchmarking); key/value, returns MSM_AMD_EINVAL for unknown keys */

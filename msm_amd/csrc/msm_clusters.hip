@@ -560,7 +560,7 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {
 // their shift code in the top bits.
 __global__ __launch_bounds__(256) void k_cl_list(ClusterGeom g, ClusterBuffers b, double a, double a2, int n_owned) {
     const int lane = threadIdx.x & 63;
-    const int icl = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int icl = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int ncl = b.clstart[g.ncols];
     if (icl >= ncl) return;
     // a cluster of halo copies only produces no output: no list needed (the pair kernels skip it the same way)
@@ -786,23 +786,44 @@ __global__ __launch_bounds__(256) void k_pair_clusters(ClusterGeom g, ClusterBuf
 // to the wave; survivors keep list order, so the sum order is fixed.  Energy bookkeeping as in k_pair_clusters.
 #define CLQ_CAP 128 // queue entries per wave: fewer than 64 pending + 64 new
 #define CLQ_U 4 // groups per unrolled step of the pair arithmetic (2..4 and 4..6 waves per SIMD all time the same)
-template <int P, bool HALF>
-__global__ __launch_bounds__(256) void k_pair_clusters_filtered(ClusterGeom g, ClusterBuffers b, PairParams pp,
+template <int P, bool HALF, int WPE = 1, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB, WPE) void k_pair_clusters_filtered(ClusterGeom g, ClusterBuffers b, PairParams pp,
                                                                 double *__restrict__ acc, double *__restrict__ epart) {
-    __shared__ double4 queue[4][CLQ_CAP];
+    __shared__ double4 queue[WPB][CLQ_CAP];
     const int lane = threadIdx.x & 63, ii = lane >> 3, jj = lane & 7;
-    // A workgroup takes a run of consecutive clusters (4 per step, one per wave).  Launched with one workgroup per
-    // step this is the plain one-wave-per-cluster kernel; launched with a few workgroups per CU it leaves room on
-    // every CU for the kernels of another stream (the grid branch of a slab step), at the same speed: two waves per
-    // SIMD already keep the FP64 pipe busy.  Runs are handed out so that an XCD gets neighbouring clusters.
-    const int nsteps = (g.max_clusters + 3) / 4, per = (nsteps + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int step0 = xcd_remap(blockIdx.x, gridDim.x) * per, step1 = min(nsteps, step0 + per);
+    // A workgroup takes a run of consecutive clusters (WPB per step, one per wave).  Launched with one workgroup per
+    // step this is the plain one-wave-per-cluster kernel; launched with a few workgroups per CU (WPB = 4 only) it leaves
+    // room on every CU for the kernels of another stream, at the same speed.  Runs are handed out so that an XCD gets
+    // neighbouring clusters.  Workgroups of one wave are the default: the waves of a four-wave workgroup are placed
+    // together, one per SIMD whatever the SIMDs hold, and the per-wave clocks (msm_amd_set_pair_trace) showed SIMDs
+    // ending up with 10 to 24 evaluated waves on a slab rank and at most three resident where four fit (the 4-wave
+    // instantiation of order 6 also needs 129 registers, one too many for four); single waves go where there is room:
+    // 0.773 -> 0.705 ms for 1M particles, 148 -> 129 us on a rank of 8.
+    // The launch covers the cluster slots the buffers can hold; the clusters there are come first, and a slab rank, which
+    // is created with headroom, has 6 % fewer: the runs are dealt out over the live steps only (an XCD would else get an
+    // eighth of the slots, and the last one the empty ones), the steps behind them keep their own number.
+    const int nsteps = (g.max_clusters + WPB - 1) / WPB, per = (nsteps + (int)gridDim.x - 1) / (int)gridDim.x;
     const int ncl = b.clstart[g.ncols];
+    const int nlive = (ncl + WPB - 1) / WPB;
+    int step0 = xcd_remap(blockIdx.x, gridDim.x) * per;
+    if (per == 1) step0 = (int)blockIdx.x < nlive ? xcd_remap(blockIdx.x, nlive) : (int)blockIdx.x;
+    const int step1 = min(nsteps, step0 + per);
     for (int step = step0; step < step1; step++) [&] {
-    const int icl = __builtin_amdgcn_readfirstlane(step * 4 + (threadIdx.x >> 6));
+    const int icl = __builtin_amdgcn_readfirstlane(step * WPB + (threadIdx.x >> 6));
     if (icl >= g.max_clusters) return;
+    const unsigned long long t_start = b.trace ? wall_clock64() : 0ull;
+    auto trace = [&](unsigned long long kind) {
+        if (b.trace && lane == 0) {
+            unsigned long long *t = b.trace + 4 * (size_t)icl;
+            t[0] = t_start;
+            t[1] = wall_clock64();
+            t[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+            t[3] = kind;
+        }
+    };
     if (icl >= ncl) {
         if (lane == 0) epart[icl] = 0.0;
+        trace(1);
         return;
     }
     const int nu = b.n0[icl], ns = b.n1[icl], nd = b.n2[icl];
@@ -810,6 +831,7 @@ __global__ __launch_bounds__(256) void k_pair_clusters_filtered(ClusterGeom g, C
     const LaneI I = load_lane_i(g, b, pp, icl, ii);
     if (!__ballot(I.owned)) {
         if (lane == 0) epart[icl] = 0.0;
+        trace(2);
         return;
     }
     const int S = g.list_stride, MID = S / 2;
@@ -920,6 +942,7 @@ __global__ __launch_bounds__(256) void k_pair_clusters_filtered(ClusterGeom g, C
     else walk(L + MID, 1, nd, false, No{}, uh);
     walk(L + S - 1, -1, ns, true, No{}, uh);
     cl_finish(I, pp, jj, icl, 2.0 * u1 + uh, fx, fy, fz, acc, epart, lane);
+    trace(3);
     }();
 }
 
@@ -1187,8 +1210,10 @@ __global__ __launch_bounds__(256) void k_pair_clusters_overflow(ClusterGeom g, C
 }
 
 void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double *acc,
-                          double *epart, int variant, int n_total, hipEvent_t *ev, int max_wgs, hipEvent_t after_lists) {
+                          double *epart, int variant, int n_total, hipEvent_t *ev, int max_wgs, hipEvent_t after_lists, int lds_pad_wpe) {
     const double a = sqrt(pp.a2);
+    // A/B: unused LDS per workgroup, waves per workgroup of the list-walking kernel (0: one), of the list build (0: four)
+    const int lds_pad = lds_pad_wpe & 0xFFFFF, wpb = (lds_pad_wpe >> 20) & 0xF, list_wpb = (lds_pad_wpe >> 24) & 0xF;
     const int nblk = (g.max_clusters + 3) / 4;
     const int nwg = max_wgs > 0 ? std::min(nblk, max_wgs) : nblk; // workgroups of the list-walking kernel (it loops over its share)
     const int half = pp.n_owned >= n_total ? 1 : 0; // every particle owned: pair energies are taken from one side
@@ -1198,7 +1223,8 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
         else hipLaunchKernelGGL((k_pair_clusters_direct<6>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart, half);
         return;
     }
-    hipLaunchKernelGGL(k_cl_list, dim3(nblk), dim3(256), 0, st, g, b, a, pp.a2, pp.n_owned);
+    if (list_wpb == 1) hipLaunchKernelGGL(k_cl_list, dim3(g.max_clusters), dim3(64), 0, st, g, b, a, pp.a2, pp.n_owned);
+    else hipLaunchKernelGGL(k_cl_list, dim3(nblk), dim3(256), 0, st, g, b, a, pp.a2, pp.n_owned);
     if (after_lists) hipEventRecord(after_lists, st); // lets another stream start beside the pair kernel, not beside the list build
 #define LAUNCH_PC(P, HALF, U)                                                                                  \
     do {                                                                                                       \
@@ -1210,7 +1236,9 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
 #define LAUNCH_PF(P, HALF)                                                                                          \
     do {                                                                                                            \
         if (ev) hipEventRecord(ev[0], st);                                                                          \
-        hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF>), dim3(nwg), dim3(256), 0, st, g, b, pp, acc, epart); \
+        if (max_wgs > 0 || wpb == 4) hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF, 1, 4>), dim3(nwg), dim3(256), lds_pad, st, g, b, pp, acc, epart); \
+        else if (wpb == 2) hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF, 1, 2>), dim3((g.max_clusters + 1) / 2), dim3(128), lds_pad, st, g, b, pp, acc, epart); \
+        else hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF, 1, 1>), dim3(g.max_clusters), dim3(64), lds_pad, st, g, b, pp, acc, epart); \
         if (ev) hipEventRecord(ev[1], st);                                                                          \
     } while (0)
     if (variant == 4 && g.max_clusters < (1 << 24)) { // particle granularity, survivors split by the half of i they are near

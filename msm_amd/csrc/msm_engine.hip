@@ -92,6 +92,7 @@ struct msm_amd_handle {
     hipEvent_t pairs_after = nullptr; // set for one msm_amd_stage_pairs call: recorded between the list build and the pair kernel
     int opt_conv_sym = 2;       // tiled convolution: mirror columns of a stencil share their multiplications (2: and 16 outputs per thread; 0: off)
     int opt_transfer_chain = 1; // two prolongations per launch where the grids allow it
+    int opt_conv_tile_planes = 0; // slab ranks: planes per tile of k_conv_split (0: chosen per launch)
     int opt_conv_groups = 1;  // slab ranks: the level-0 convolution by k_conv_split
     int opt_slab_level1 = 1;  // slab ranks: level 1 convolved on the planes under the rank's own only
     int opt_grid_streams = 0; // measured: slower (1.68 vs 1.65 ms at 1M; the chain of small kernels does not get CUs while the
@@ -100,10 +101,14 @@ struct msm_amd_handle {
     double *conv_part = nullptr; // partial sums of a level-0 convolution whose taps are shared out over workgroups (4 grids)
     int opt_conv_split = 0;      // 0: never (default: measured slower, 128 against 108 us for 18 planes of 96 x 96 in three shares);
                                  // 1: when a slab rank has few tiles; n > 1: that many shares
+    int opt_pair_lds_pad = 0; // unused LDS per workgroup of the pair kernel, bytes: caps its waves per SIMD (16 KB are its own)
+    int opt_pair_wpb = 0;     // A/B: waves per workgroup of the list-walking pair kernel (0: one; 2, 4)
+    int opt_list_wpb = 0;     // A/B: waves per workgroup of the list build (0: four; 1)
     int pair_wgs_now = 0;     // A/B: cap on the workgroups of the pair kernel (0: one workgroup per four clusters; measured
                               // slower at 2, 3 and 4 workgroups per CU, and kernels of a second stream gain nothing from the room)
-    int opt_slab_overlap = 1; // slab step: the charge exchange on a second stream beside the pair sum (0: one stream, for several
-                              // processes sharing one GPU, where cross-stream waits were seen to stall)
+    int opt_slab_overlap = 2; // slab step: the charge exchange on a second stream beside the pair sum (0: one stream, for several
+                              // processes sharing one GPU, where cross-stream waits were seen to stall); 2: and the chain of the
+                              // coarser levels behind it on that stream (-16 / -12 / -23 us at 8 / 4 / 2 ranks)
     // parts of the grid branch on a second stream beside the pair branch: 1 all of it (slower: the level-0 convolution
     // wants the FP64 pipe the pair kernel is using), 2 the anterpolation (bound by the LDS port: -22 us), 3 and the chain
     // of the coarser levels (-35 us), 4 as 3, from the end of the list build on.  0: the stage times and the pair
@@ -549,6 +554,10 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "overlap")) { h->opt_overlap = value; return MSM_AMD_OK; }
     if (!strcmp(key, "slab_overlap")) { h->opt_slab_overlap = value; return MSM_AMD_OK; }
     if (!strcmp(key, "conv_split")) { h->opt_conv_split = value; return MSM_AMD_OK; }
+    if (!strcmp(key, "conv_tile_planes")) { if (value == 0 || value == 8 || value == 9 || value == 12) { h->opt_conv_tile_planes = value; return MSM_AMD_OK; } }
+    if (!strcmp(key, "pair_lds_pad")) { if (value >= 0 && value <= 48 * 1024) { h->opt_pair_lds_pad = value; return MSM_AMD_OK; } }
+    if (!strcmp(key, "pair_wpb")) { if (value == 0 || value == 1 || value == 2 || value == 4) { h->opt_pair_wpb = value; return MSM_AMD_OK; } }
+    if (!strcmp(key, "list_wpb")) { if (value == 0 || value == 1 || value == 4) { h->opt_list_wpb = value; return MSM_AMD_OK; } }
     if (!strcmp(key, "pair_wgs")) { h->pair_wgs_now = value; return MSM_AMD_OK; } // A/B: cap on the pair kernel's workgroups
     if (!strcmp(key, "top_fused")) { h->opt_top_fused = value; return MSM_AMD_OK; }
     if (!strcmp(key, "grid_streams")) { h->opt_grid_streams = value; return MSM_AMD_OK; }
@@ -624,7 +633,7 @@ extern "C" int msm_amd_stage_pairs(msm_amd_handle *h, double *d_acc) {
             launch_cluster_sort(h->stream, h->cur_r, h->cur_q, h->N, h->clg, h->clb, h->bin_of, h->arrival, h->slot_idx, h->scan_tmp);
         h->clusters_sorted = true;
         launch_pair_clusters(h->stream, h->clg, h->clb, h->pp, d_acc, h->epart, h->opt_pair_variant - 5, h->N,
-                             h->profiling ? h->ev_pk : nullptr, h->pair_wgs_now, h->pairs_after);
+                             h->profiling ? h->ev_pk : nullptr, h->pair_wgs_now, h->pairs_after, h->opt_pair_lds_pad | (h->opt_pair_wpb << 20) | (h->opt_list_wpb << 24));
         h->pairs_after = nullptr;
         h->pk_recorded = h->profiling && h->opt_pair_variant != 6;
         h->nepart = h->clg.max_clusters;
@@ -747,6 +756,7 @@ static void convolve_ranges(msm_amd_handle *h, const std::vector<PlaneRange> &ra
         B.n = 0;
         B.split = h->opt_conv_groups;
         B.sym = h->opt_conv_sym;
+        B.tile_planes = h->opt_conv_tile_planes;
         std::vector<size_t> members;
         // A slab rank convolves a few planes of level 0: fewer tiles (16 x 8 x 16 outputs each) than the chip has CUs,
         // so the kernel lasts as long as one workgroup needs for all taps of its tile.  The taps are then shared out
@@ -1285,6 +1295,7 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
     h->pk_recorded = false;
     hipStream_t a = h->stream, b = two ? h->stream_b : h->stream;
     const size_t plane = (size_t)d.M[0] * d.M[1];
+    bool coarse_on_b = false;
     if ((rc = msm_amd_stage_bin(h, d_r, d_q))) return rc;
     if ((rc = msm_amd_stage_anterpolate(h))) return rc;
     if (two) {
@@ -1322,13 +1333,18 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
             }
             if (!rc) rc = grid_front(h, coll);
         }
+        // 2: the chain of the coarser levels (restrictions, their convolutions, top level, prolongations down to level 1:
+        // small kernels that each last as long as a launch) follows the exchange on the second stream, beside the pair
+        // sum; the first stream is left with the level-0 convolution and the last prolongation
+        coarse_on_b = two && h->opt_slab_overlap == 2 && d.L >= 2 && !h->profiling;
+        if (!rc && coarse_on_b) rc = grid_stage(h, xmode == MSM_AMD_SLAB_HALO, 1);
         if (!rc && two && hipEventRecord(h->ev_join, b) != hipSuccess) { set_error("slab step: hipEventRecord failed"); rc = MSM_AMD_EHIP; }
         h->stream = a;
         if (rc) return rc;
     }
     if ((rc = msm_amd_stage_pairs(h, d_acc))) return rc;
     if (two) HIPCHK(hipStreamWaitEvent(a, h->ev_join, 0));
-    if ((rc = grid_stage(h, slab && xmode == MSM_AMD_SLAB_HALO))) return rc;
+    if ((rc = grid_stage(h, slab && xmode == MSM_AMD_SLAB_HALO, coarse_on_b ? 2 : 0))) return rc;
     if ((rc = msm_amd_stage_interpolate(h, d_acc))) return rc;
     if ((rc = queue_energies(h, true))) return rc;
     if (coll && world > 1 && coll->all_reduce_sum(coll->ctx, h->d_energies, 5, (void *)a)) {
@@ -1453,6 +1469,15 @@ extern "C" int msm_amd_write_msmsimple_cache(msm_amd_handle *h, const char *dir)
     if (!h) return MSM_AMD_EINVAL;
     return write_msmsimple_cache(h->hp, dir);
 }
+
+// profiling hook: a device buffer of 4 x 64-bit words per cluster slot (msm_amd_pair_trace_slots of them) that the
+// list-walking pair kernel fills per wave with {start, end (100 MHz clock), hardware ids, kind}; NULL switches it off
+extern "C" int msm_amd_set_pair_trace(msm_amd_handle *h, void *d_buffer) {
+    if (!h) return MSM_AMD_EINVAL;
+    h->clb.trace = (unsigned long long *)d_buffer;
+    return MSM_AMD_OK;
+}
+extern "C" long msm_amd_pair_trace_slots(msm_amd_handle *h) { return h ? (long)h->clg.max_clusters : 0; }
 
 extern "C" int msm_amd_last_timings(msm_amd_handle *h, double ms[10]) {
     if (!h || !ms) return MSM_AMD_EINVAL;

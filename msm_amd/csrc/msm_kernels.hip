@@ -1789,9 +1789,9 @@ static bool conv_multi_launch(hipStream_t st, ConvBatch &B) {
 // LDS at the end and are added in the order of the groups.  Four waves per SIMD hide what k_conv_multi hides by
 // prefetching, so the loop is the plain one.
 
-template <int SZ, int G, int CH, bool SYM = false>
+template <int SZ, int G, int CH, bool SYM = false, int R = 8>
 __global__ __launch_bounds__(128 * G, 4) void k_conv_split(ConvBatch B) {
-    constexpr int R = 8, TX = 16, TY = 8, TZ = 8;
+    constexpr int TX = 16, TY = 8, TZ = R;
     extern __shared__ double lds[];
     int lev = 0;
     while (lev + 1 < B.n && (int)blockIdx.x >= B.blk0[lev + 1]) lev++;
@@ -1925,13 +1925,13 @@ __global__ __launch_bounds__(128 * G, 4) void k_conv_split(ConvBatch B) {
     }
 }
 
-template <int SZ, int G, int CH, bool SYM = false>
+template <int SZ, int G, int CH, bool SYM = false, int R = 8>
 static bool conv_split_launch(hipStream_t st, ConvBatch &B) {
-    constexpr int TX = 16, TY = 8, TZ = 8, CHR = CH < SZ ? CH : SZ;
+    constexpr int TX = 16, TY = 8, TZ = R, CHR = CH < SZ ? CH : SZ;
     constexpr int LX = TX + SZ - 1, LY = ((TY + CHR - 1 + 1) / 4) * 4 + 2, LZ = TZ + SZ - 1;
     constexpr size_t bytes = sizeof(double) * (size_t)LX * LY * LZ;
-    static_assert(bytes <= 80 * 1024, "two workgroups to a CU");
-    static_assert(bytes >= sizeof(double) * (G - 1) * 8 * 128, "the partial sums fit the tile");
+    static_assert(bytes <= (R == 8 ? 80 : 160) * 1024, "two workgroups of the 8-plane tile to a CU, one of the taller ones");
+    static_assert(bytes >= sizeof(double) * (G - 1) * R * 128, "the partial sums fit the tile");
     int nblk = 0;
     for (int l = 0; l < B.n; l++) {
         const ConvArgs &c = B.c[l];
@@ -1943,7 +1943,7 @@ static bool conv_split_launch(hipStream_t st, ConvBatch &B) {
     }
     B.blk0[B.n] = nblk;
     if (nblk == 0) return false;
-    auto kern = k_conv_split<SZ, G, CH, SYM>;
+    auto kern = k_conv_split<SZ, G, CH, SYM, R>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
@@ -1966,6 +1966,30 @@ bool launch_conv_multi(hipStream_t st, ConvBatch &B) {
     for (int l = 0; l < B.n; l++) centred = centred && (B.c[l].ks[0] & 1) && B.c[l].kf[0] == -(B.c[l].ks[0] / 2);
     if (!centred) B.sym = 0;
     if (!cubes && (B.split > 1 || (B.split && B.c[0].nz < B.c[0].M[2]))) { // a slab of planes (or on request)
+        if (B.c[0].ks[2] == 15 && B.sym) {
+            // Planes per tile.  Up to 256 workgroups run one to a CU and the launch lasts as long as one of them:
+            // 12 + 4.5 us per plane of the tile, measured (the window reads from LDS and the FMAs take equally long and
+            // do not overlap).  Beyond that some CUs run two at a time, which takes 1.4 times one of them if their LDS
+            // tiles fit side by side and twice otherwise.  18 planes of 96 x 96 nodes (a rank of 8) are two layers of 9
+            // planes, 198 workgroups with the coarser levels and 52 us, against three layers of 8, 288 workgroups and
+            // 64 us; at 4 and 2 ranks tiles of 8 planes stay the best (9: +6 us, 12: +60, 15: +14 at 4 ranks).
+            const int heights[3] = {8, 9, 12};
+            int best = 8;
+            double best_cost = 0;
+            for (int k = 0; k < 3; k++) {
+                const int r = heights[k];
+                long n = 0;
+                for (int l = 0; l < B.n; l++)
+                    n += (long)((B.c[l].M[0] + 15) / 16) * ((B.c[l].M[1] + 7) / 8) * ((B.c[l].nz + r - 1) / r);
+                const bool two_fit = 2 * 30 * 14 * (r + 14) * 8 <= 160 * 1024;
+                const double one = 12.0 + 4.5 * r;
+                const double cost = n <= 256 ? one : (two_fit ? 1.4 * (double)((n + 511) / 512) : (double)((n + 255) / 256)) * one;
+                if (k == 0 || cost < 0.9 * best_cost) { best = r; best_cost = cost; }
+            }
+            if (B.tile_planes) best = B.tile_planes; // A/B
+            if (best == 9 && conv_split_launch<15, 4, 5, true, 9>(st, B)) return true;
+            if (best == 12 && conv_split_launch<15, 4, 5, true, 12>(st, B)) return true;
+        }
         if (B.c[0].ks[2] == 15 && B.sym && conv_split_launch<15, 4, 5, true>(st, B)) return true;
         if (B.c[0].ks[2] == 15 && conv_split_launch<15, 4, 5>(st, B)) return true;
         if (B.c[0].ks[2] == 19 && B.sym && conv_split_launch<19, 4, 3, true>(st, B)) return true;

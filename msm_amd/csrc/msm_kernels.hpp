@@ -102,6 +102,9 @@ struct ClusterBuffers {
     int *hist, *coltotal, *cpstart;
     double4 *bps;
     int2 *bkey;                 // (original index, fine bin inside the column) of a bucket entry
+    // profiling hook (null unless msm_amd_set_pair_trace gave a buffer): per cluster slot the 100 MHz clock at the start
+    // and the end of its wave in the list-walking pair kernel, the hardware id of the wave and of its XCD
+    unsigned long long *trace;
 };
 void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, int N, const ClusterGeom &g,
                          const ClusterBuffers &b, int *bin_of, int *arrival, int *slot_idx, int *scan_tmp);
@@ -111,7 +114,8 @@ void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, i
 // max_wgs > 0 caps the workgroups of the list-walking kernel (variant 3), which then loops over its clusters
 // after_lists (optional): an event recorded between the list build and the pair kernel
 void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double *acc,
-                          double *epart, int variant, int n_total, hipEvent_t *ev, int max_wgs = 0, hipEvent_t after_lists = nullptr);
+                          double *epart, int variant, int n_total, hipEvent_t *ev, int max_wgs = 0, hipEvent_t after_lists = nullptr,
+                          int lds_pad = 0); // lds_pad: unused LDS bytes per workgroup of the list-walking kernel (caps the waves per SIMD)
 
 // ---- short range ----
 void launch_pair_cells(hipStream_t st, const double4 *ps, const int *cstart, const int *order, int ncell,
@@ -171,6 +175,7 @@ struct ConvBatch {
     int n;
     int split = 0;       // a slab of planes on level 0: tiles of 8 planes whose stencil columns are shared out over wave groups
     int sym = 0;         // in: the caller allows the mirror symmetry of the stencils along x to be used (sums in another order)
+    int tile_planes = 0; // in: planes per tile of the slab kernel (8, 9, 12; 0: chosen from the number of workgroups)
     int blk0[9];
     int ntx[8], nty[8];
     ConvArgs c[8];

@@ -7,12 +7,7 @@ import msm_amd
 from msm_amd.slab import SlabRank, NullCollectives
 from bench import make_system, SlabProfiler
 
-class FakeWork:
-    def wait(self): pass
-class FakeDist:
-    def get_backend(self): return "nccl"
-    def all_gather_into_tensor(self, out, inp, async_op=False): return FakeWork()
-    def all_reduce(self, t, async_op=False): return None
+from rank_sim_common import FakeDist
 
 N = int(os.environ.get("RANK_SIM_N", "1000000")); p = int(sys.argv[2]) if len(sys.argv) > 2 else 6   # RANK_SIM_N: particles of the whole system
 W = int(sys.argv[1])
