@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pair-variant", type=int, default=-1)
     ap.add_argument("--no-accuracy", action="store_true", help="skip the Ewald reference (error of the MSM result)")
+    ap.add_argument("--opts", default="", help="engine options for A/B runs, key=value,key=value (msm_amd_set_option)")
     args = ap.parse_args()
 
     import torch
@@ -114,6 +115,10 @@ def main():
         if args.pair_variant >= 0:
             eng.set_option("pair_variant", args.pair_variant)
         stepper.profile = SlabProfiler(torch, stepper).profile
+
+    for kv in filter(None, args.opts.split(",")):
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
 
     exchange = ""
     if world > 1:
@@ -202,6 +207,7 @@ def main():
                                    % (N, p, "x".join(str(m) for m in desc.M), desc.L, desc.kmax),
                        "particles": N, "order": p, "levels": desc.L, "grid": list(desc.M),
                        "parallelism": "single GPU" if world == 1 else "z-slabs x%d, %s" % (world, exchange),
+                       **({"engine_options": args.opts} if args.opts else {}),
                        **({} if backend == "nccl" else {"rehearsal": "ranks share devices, %s collectives through the host: not a measurement" % backend})},
             "roofline": {"kernel": "k_pair_clusters_filtered (short-range pair sum)", "bound": "valu_fp64", "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,

@@ -554,7 +554,7 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "overlap")) { h->opt_overlap = value; return MSM_AMD_OK; }
     if (!strcmp(key, "slab_overlap")) { h->opt_slab_overlap = value; return MSM_AMD_OK; }
     if (!strcmp(key, "conv_split")) { h->opt_conv_split = value; return MSM_AMD_OK; }
-    if (!strcmp(key, "conv_tile_planes")) { if (value == 0 || value == 8 || value == 9 || value == 12) { h->opt_conv_tile_planes = value; return MSM_AMD_OK; } }
+    if (!strcmp(key, "conv_tile_planes")) { if (value == 0 || value == 6 || (value >= 8 && value <= 10) || value == 12) { h->opt_conv_tile_planes = value; return MSM_AMD_OK; } }
     if (!strcmp(key, "pair_lds_pad")) { if (value >= 0 && value <= 48 * 1024) { h->opt_pair_lds_pad = value; return MSM_AMD_OK; } }
     if (!strcmp(key, "pair_wpb")) { if (value == 0 || value == 1 || value == 2 || value == 4) { h->opt_pair_wpb = value; return MSM_AMD_OK; } }
     if (!strcmp(key, "list_wpb")) { if (value == 0 || value == 1 || value == 4) { h->opt_list_wpb = value; return MSM_AMD_OK; } }
@@ -785,8 +785,25 @@ static void convolve_ranges(msm_amd_handle *h, const std::vector<PlaneRange> &ra
         if (split > 1 && !h->conv_part) {
             if (dalloc(&h->conv_part, 4 * n0grid)) { split = 1; (void)hipGetLastError(); }
         }
-        for (size_t i = 0; i < ranges.size() && B.n < 8; i++) {
+        // A range that runs past the last plane comes as two entries, [lo, Mz) and [0, rest): the tiled kernels take it as
+        // one, [lo, lo + n) modulo Mz (two entries are two sets of tiles, and the short one fills whole tiles with a few
+        // planes: 72 workgroups more for the 3 planes of rank 0 of 8, which the rank in the middle does not have).
+        std::vector<PlaneRange> joined;
+        std::vector<std::pair<size_t, size_t>> source; // entries of `ranges` a joined entry stands for
+        for (size_t i = 0; i < ranges.size(); i++) {
             const PlaneRange &r = ranges[i];
+            if (split == 1 && i + 1 < ranges.size() && ranges[i + 1].l == r.l && ranges[i + 1].z0 == 0 &&
+                r.z0 + r.nz == h->hp.Ml[r.l][2] && r.nz + ranges[i + 1].nz <= h->hp.Ml[r.l][2]) {
+                joined.push_back({r.l, r.z0, r.nz + ranges[i + 1].nz});
+                source.push_back({i, i + 1});
+                i++;
+            } else {
+                joined.push_back(r);
+                source.push_back({i, i});
+            }
+        }
+        for (size_t i = 0; i < joined.size() && B.n < 8; i++) {
+            const PlaneRange &r = joined[i];
             const LevelStencil &S = h->hp.K[r.l];
             const int *M = h->hp.Ml[r.l];
             if (!(M[0] >= 16 && M[1] >= 8 && M[2] >= 8)) continue; // a short plane range of a large grid is fine
@@ -809,8 +826,8 @@ static void convolve_ranges(msm_amd_handle *h, const std::vector<PlaneRange> &ra
         }
         if (B.n > 0 && launch_conv_multi(st, B)) {
             for (size_t i : members) {
-                done[i] = true;
-                const PlaneRange &r = ranges[i];
+                done[source[i].first] = done[source[i].second] = true;
+                const PlaneRange &r = joined[i];
                 if (r.l == 0 && split > 1) {
                     // e = ((part 0 + part 1) + part 2) + ..., two partial grids per pass
                     const size_t plane = (size_t)h->hp.d.M[0] * h->hp.d.M[1], off = plane * r.z0, n = plane * r.nz;

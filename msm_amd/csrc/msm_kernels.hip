@@ -1460,7 +1460,8 @@ __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_tiled(const double *_
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int mz = Z0 + tg * R + r;
-            if (mz < c.z0 + c.nz && mz < Mz) e[((size_t)mz * My + my) * Mx + mx] = acc[r];
+            // (a range may run past the last plane and go on at plane 0: z0 + nz > Mz)
+            if (mz < c.z0 + c.nz) e[((size_t)(mz >= Mz ? mz - Mz : mz) * My + my) * Mx + mx] = acc[r];
         }
     }
 }
@@ -1748,7 +1749,8 @@ __global__ __launch_bounds__(TX *TY *(TZ / R)) void k_conv_multi(ConvBatch B) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int mz = Z0 + tg * R + r;
-            if (mz < c.z0 + c.nz && mz < Mz) e[((size_t)mz * My + my) * Mx + mx] = acc[r];
+            // (a range may run past the last plane and go on at plane 0: z0 + nz > Mz)
+            if (mz < c.z0 + c.nz) e[((size_t)(mz >= Mz ? mz - Mz : mz) * My + my) * Mx + mx] = acc[r];
         }
     }
 }
@@ -1920,7 +1922,7 @@ __global__ __launch_bounds__(128 * G, 4) void k_conv_split(ConvBatch B) {
 #pragma unroll
             for (int g = 1; g < G; g++) v += lds[((g - 1) * R + r) * 128 + t128];
             const int mz = Z0 + r;
-            if (mx < Mx && my < My && mz < c.z0 + c.nz && mz < Mz) e[((size_t)mz * My + my) * Mx + mx] = v;
+            if (mx < Mx && my < My && mz < c.z0 + c.nz) e[((size_t)(mz >= Mz ? mz - Mz : mz) * My + my) * Mx + mx] = v;
         }
     }
 }
@@ -1972,11 +1974,11 @@ bool launch_conv_multi(hipStream_t st, ConvBatch &B) {
             // do not overlap).  Beyond that some CUs run two at a time, which takes 1.4 times one of them if their LDS
             // tiles fit side by side and twice otherwise.  18 planes of 96 x 96 nodes (a rank of 8) are two layers of 9
             // planes, 198 workgroups with the coarser levels and 52 us, against three layers of 8, 288 workgroups and
-            // 64 us; at 4 and 2 ranks tiles of 8 planes stay the best (9: +6 us, 12: +60, 15: +14 at 4 ranks).
-            const int heights[3] = {8, 9, 12};
+            // 64 us; 18 planes of level 0 alone (the coarser levels on another stream) are three layers of 6.
+            const int heights[5] = {8, 6, 9, 10, 12};
             int best = 8;
             double best_cost = 0;
-            for (int k = 0; k < 3; k++) {
+            for (int k = 0; k < 5; k++) {
                 const int r = heights[k];
                 long n = 0;
                 for (int l = 0; l < B.n; l++)
@@ -1987,7 +1989,9 @@ bool launch_conv_multi(hipStream_t st, ConvBatch &B) {
                 if (k == 0 || cost < 0.9 * best_cost) { best = r; best_cost = cost; }
             }
             if (B.tile_planes) best = B.tile_planes; // A/B
+            if (best == 6 && conv_split_launch<15, 4, 5, true, 6>(st, B)) return true;
             if (best == 9 && conv_split_launch<15, 4, 5, true, 9>(st, B)) return true;
+            if (best == 10 && conv_split_launch<15, 4, 5, true, 10>(st, B)) return true;
             if (best == 12 && conv_split_launch<15, 4, 5, true, 12>(st, B)) return true;
         }
         if (B.c[0].ks[2] == 15 && B.sym && conv_split_launch<15, 4, 5, true>(st, B)) return true;

@@ -11,13 +11,14 @@ from rank_sim_common import FakeDist
 
 N = int(os.environ.get("RANK_SIM_N", "1000000")); p = int(sys.argv[2]) if len(sys.argv) > 2 else 6   # RANK_SIM_N: particles of the whole system
 W = int(sys.argv[1])
+RANK = int(os.environ.get("RANK_SIM_RANK", str(W // 2)))   # which rank's work (rank 0 and the last one own planes that wrap around the period)
 r, q = make_system(N, 20261113)
 desc = msm_amd.plan_auto(N, (1.0, 1.0, 1.0), p, 10, 4.0, 0)
 # argv[4]: exchange mode (0 auto, 1 all-gather, 2 halo); argv[5] == "py": the stage-by-stage Python step instead of the C step
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 c_step = not (len(sys.argv) > 5 and sys.argv[5] == "py")
-s = SlabRank(torch, FakeDist(), msm_amd, desc, r, q, W // 2, W, 0, perturb=True, mode=mode,
-             collectives=NullCollectives(W // 2, W) if W > 1 else None, c_step=c_step)
+s = SlabRank(torch, FakeDist(), msm_amd, desc, r, q, RANK, W, 0, perturb=True, mode=mode,
+             collectives=NullCollectives(RANK, W) if W > 1 else None, c_step=c_step)
 for kv in filter(None, (sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else "").split(",")):   # engine options: key=value,key=value
     k, v = kv.split("=")
     s.eng.set_option(k, int(v))
@@ -28,4 +29,4 @@ for _ in range(20): s.step(want_energies=False)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 20
 prof = SlabProfiler(torch, s).profile(5)
-print("N", N, "M", list(desc.M), "W", W, "p", p, "mode", s.eng.slab_exchange_mode(W, mode) if W > 1 else "-", "c_step", s.coll is not None, "n_own", s.n_own, "n_tot", s.n_tot, "ms/step", round(dt * 1e3, 3), {k: round(v, 3) for k, v in prof.items()})
+print("N", N, "M", list(desc.M), "W", W, "rank", RANK, "p", p, "mode", s.eng.slab_exchange_mode(W, mode) if W > 1 else "-", "c_step", s.coll is not None, "n_own", s.n_own, "n_tot", s.n_tot, "ms/step", round(dt * 1e3, 3), {k: round(v, 3) for k, v in prof.items()})
