@@ -162,6 +162,8 @@ SIGNATURES = {
     "msm_amd_last_timings": (C.c_int, [_vp, _dp]),
     "msm_amd_last_kernel_ms": (C.c_int, [_vp, C.c_char_p, _dp]),
     "msm_amd_set_profiling": (None, [_vp, C.c_int]),
+    "msm_amd_set_pair_trace": (C.c_int, [_vp, _vp]),
+    "msm_amd_pair_trace_slots": (C.c_long, [_vp]),
     "msm_amd_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "msm_amd_hostplan_create": (C.c_int, [C.POINTER(PlanDesc), C.c_int, _vpp]),
     "msm_amd_hostplan_write_msmsimple_cache": (C.c_int, [_vp, C.c_char_p]),

@@ -19,9 +19,6 @@ for kv in filter(None, (sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "-" 
     k, v = kv.split("=")
     s.eng.set_option(k, int(v))
 lib = capi.load()
-lib.msm_amd_pair_trace_slots.restype = C.c_long
-lib.msm_amd_pair_trace_slots.argtypes = [C.c_void_p]
-lib.msm_amd_set_pair_trace.argtypes = [C.c_void_p, C.c_void_p]
 slots = lib.msm_amd_pair_trace_slots(s.eng._h)
 for _ in range(3): s.step(want_energies=False)
 torch.cuda.synchronize()
