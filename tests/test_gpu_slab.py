@@ -338,3 +338,80 @@ def test_open_boundary_slabs_match_single_gpu(tmp_path):
     assert planes == desc.M[2] and (seen == 1).all()
     assert max(counts) < 1.2 * min(counts), counts            # balanced by particle count, not by planes
     assert np.sqrt(((acc - acc1) ** 2).sum() / (acc1 ** 2).sum()) < 1e-12
+
+
+class _NoDist:
+    """torch.distributed stand-in for a rank that runs alone (the collectives are a table of no-ops)."""
+
+    def get_backend(self):
+        return "nccl"
+
+
+def _one_rank_steps(rank, world, options, steps=3):
+    """`steps` evaluations of one rank of `world` with collectives that move nothing: the planes of the other ranks keep
+    what they held, which depends only on the rank's own history, so two runs of the same history give the same bits
+    whichever stream or launch shape the engine's options pick."""
+    import torch
+    import msm_amd
+    from msm_amd.slab import SlabRank, NullCollectives
+    N, desc = _plan(msm_amd, ("explicit", 100000, 6, 4, 96, 0.04))
+    r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=47)
+    s = SlabRank(torch, _NoDist(), msm_amd, desc, r, q, rank, world, 0, perturb=False, collectives=NullCollectives(rank, world))
+    assert s.eng.slab_exchange_mode(world, 0) == 2          # halo exchange: the step with the most stages in flight
+    for k, v in options.items():
+        s.eng.set_option(k, v)
+    for _ in range(steps):
+        s.step(want_energies=False)
+    torch.cuda.synchronize()
+    return s.acc[:s.n_own].clone(), s.sums.clone()
+
+
+@pytest.mark.parametrize("rank", [0, 2])
+def test_slab_step_options_keep_the_bits(rank):
+    """The slab step with the coarse-level chain on the exchange stream (slab_overlap 2, the default), with the exchange
+    alone there (1) and on one stream (0); the slab convolution in tiles of 6 to 12 planes; the pair kernel in workgroups
+    of 1, 2 and 4 waves: the same kernels on the same data, so accelerations and raw sums agree bit for bit.  Rank 0 owns
+    planes whose halo wraps around the period (one plane range for the convolution), rank 2 does not."""
+    import torch
+    world = 4
+    ref_acc, ref_sums = _one_rank_steps(rank, world, {})
+    assert torch.isfinite(ref_acc).all() and float(ref_acc.abs().max()) > 0
+    cases = [{"slab_overlap": 0}, {"slab_overlap": 1}, {"conv_tile_planes": 6}, {"conv_tile_planes": 8}, {"conv_tile_planes": 9},
+             {"conv_tile_planes": 10}, {"conv_tile_planes": 12, "slab_overlap": 1}, {"pair_wpb": 2}, {"pair_wpb": 4},
+             {"list_wpb": 1}, {"pair_lds_pad": 17408}]
+    for opts in cases:
+        acc, sums = _one_rank_steps(rank, world, opts)
+        assert torch.equal(acc, ref_acc), opts
+        assert torch.equal(sums, ref_sums), opts
+
+
+def test_pair_trace_hook():
+    """msm_amd_set_pair_trace: every wave of the pair kernel leaves {start, end, hardware id, kind}; the evaluation's
+    results do not change, and the hook is off again after NULL."""
+    import ctypes as C
+    import torch
+    import msm_amd
+    N = 60000
+    desc = msm_amd.plan_auto(N, (1.0, 1.0, 1.0), 6, 10, 4.0, 3)
+    r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=5)
+    eng = msm_amd.Engine(desc)
+    en0, acc0 = eng.eval(r, q)
+    lib = msm_amd.load()
+    slots = lib.msm_amd_pair_trace_slots(eng._h)
+    assert slots >= N // 8
+    buf = torch.zeros((slots, 4), dtype=torch.int64, device="cuda")
+    assert lib.msm_amd_set_pair_trace(eng._h, C.c_void_p(buf.data_ptr())) == 0
+    en1, acc1 = eng.eval(r, q)
+    assert lib.msm_amd_set_pair_trace(eng._h, None) == 0
+    t = buf.cpu().numpy()
+    kinds = t[:, 3]
+    assert set(np.unique(kinds)) <= {0, 1, 3}                     # every particle is owned: no wave of halo copies only
+    done = kinds == 3
+    assert N / 8 <= done.sum() <= slots
+    assert (t[done, 1] >= t[done, 0]).all() and (t[done, 0] > 0).all()
+    assert len(np.unique((t[done, 2] >> 32) & 0xF)) == 8        # waves on all eight XCDs
+    assert np.array_equal(en0, en1) and torch.equal(acc0, acc1)
+    buf.zero_()
+    eng.eval(r, q)
+    torch.cuda.synchronize()
+    assert int(buf.abs().sum()) == 0
