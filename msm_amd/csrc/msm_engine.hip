@@ -87,6 +87,8 @@ struct msm_amd_handle {
     // second stream: the grid pipeline runs beside the list build and the pair kernel
     double *energies_alias = nullptr; // device-visible host slot the energies of the evaluation in flight go to
     hipStream_t stream_b = nullptr;
+    hipStream_t stream_a = nullptr; // slab step of a handle on the default stream: the stream its first branch runs on instead
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
     hipStream_t stream_g = nullptr; // coarse-level branch of the grid stage
     hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr;
     hipEvent_t pairs_after = nullptr; // set for one msm_amd_stage_pairs call: recorded between the list build and the pair kernel
@@ -106,9 +108,15 @@ struct msm_amd_handle {
     int opt_list_wpb = 0;     // A/B: waves per workgroup of the list build (0: four; 1)
     int pair_wgs_now = 0;     // A/B: cap on the workgroups of the pair kernel (0: one workgroup per four clusters; measured
                               // slower at 2, 3 and 4 workgroups per CU, and kernels of a second stream gain nothing from the room)
-    int opt_slab_overlap = 2; // slab step: the charge exchange on a second stream beside the pair sum (0: one stream, for several
-                              // processes sharing one GPU, where cross-stream waits were seen to stall); 2: and the chain of the
-                              // coarser levels behind it on that stream (-16 / -12 / -23 us at 8 / 4 / 2 ranks)
+    int opt_slab_own_stream = 1; // slab step of a handle on the default stream: on streams of its own (0: as given, A/B)
+    int opt_slab_overlap = -1; // slab step, what runs on a second stream beside the list build and the pair sum: 0 nothing (one
+                              // stream: for several processes sharing one GPU, where cross-stream waits were seen to stall);
+                              // 1 the charge exchange; 2 and the chain of the coarser levels behind it (-16 / -12 / -23 us at
+                              // 8 / 4 / 2 ranks of 1M particles); 3 and the level-0 convolution and the last prolongation, i.e.
+                              // the whole grid stage (a further -21 us at 8 ranks, nothing at 4, +35 us at 2, where a
+                              // convolution of 54 planes competes with the pair kernel; 10M particles, 8 ranks: -1 %);
+                              // 4 and the anterpolation (slower everywhere); -1: 3 for a rank that owns at most an eighth of
+                              // the planes, else 2
     // parts of the grid branch on a second stream beside the pair branch: 1 all of it (slower: the level-0 convolution
     // wants the FP64 pipe the pair kernel is using), 2 the anterpolation (bound by the LDS port: -22 us), 3 and the chain
     // of the coarser levels (-35 us), 4 as 3, from the end of the list build on.  0: the stage times and the pair
@@ -505,6 +513,11 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
         hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_pairs); hipEventDestroy(h->ev_join);
         hipStreamDestroy(h->stream_b);
     }
+    if (h->stream_a) {
+        hipStreamSynchronize(h->stream_a);
+        hipEventDestroy(h->ev_in); hipEventDestroy(h->ev_out);
+        hipStreamDestroy(h->stream_a);
+    }
     if (h->ev_made) { for (int i = 0; i <= T_COUNT; i++) hipEventDestroy(h->ev[i]); hipEventDestroy(h->ev_pk[0]); hipEventDestroy(h->ev_pk[1]); }
     delete h;
 }
@@ -552,6 +565,7 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "anterp_cols_order4")) { h->sopt.anterp_cols_order4 = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "anterp_cols")) { h->sopt.anterp_cols = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "overlap")) { h->opt_overlap = value; return MSM_AMD_OK; }
+    if (!strcmp(key, "slab_own_stream")) { h->opt_slab_own_stream = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "slab_overlap")) { h->opt_slab_overlap = value; return MSM_AMD_OK; }
     if (!strcmp(key, "conv_split")) { h->opt_conv_split = value; return MSM_AMD_OK; }
     if (!strcmp(key, "conv_tile_planes")) { if (value == 0 || value == 6 || (value >= 8 && value <= 10) || value == 12) { h->opt_conv_tile_planes = value; return MSM_AMD_OK; } }
@@ -961,7 +975,8 @@ static int grid_stage(msm_amd_handle *h, bool front_done, int part = 0) {
     if (two && !h->stream_g) {
         int prio_lo = 0, prio_hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        HIPCHK(hipStreamCreateWithPriority(&h->stream_g, hipStreamNonBlocking, prio_hi));
+        HIPCHK(hipStreamCreateWithFlags(&h->stream_g, hipStreamNonBlocking)); // (no priority: see ensure_stream_b)
+        (void)prio_hi;
         HIPCHK(hipEventCreateWithFlags(&h->ev_gfork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_gjoin, hipEventDisableTiming));
     }
@@ -1105,13 +1120,19 @@ static bool can_overlap(const msm_amd_handle *h) {
            h->opt_pair_variant >= 5 && h->pp.convention != MSM_AMD_ACC_LITERAL;
 }
 
-// second stream for the grid branch: highest priority, its workgroups are short-lived and should not queue behind the
-// pair kernel's
+// second stream for the grid branch
 static int ensure_stream_b(msm_amd_handle *h) {
     if (h->stream_b) return MSM_AMD_OK;
     int prio_lo = 0, prio_hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    HIPCHK(hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, prio_hi));
+    // No stream priority unless asked for (MSM_AMD_STREAM_B_PRIORITY=high, for A/B runs).  With the highest priority the
+    // short kernels of this stream get their CUs sooner beside the pair kernel (a rank of 8: -7 to -14 us per step, a
+    // rank of 2: -19 to -35 us), but in a process that had initialised RCCL and spawned children before, a step with a
+    // high-priority second stream never finished: the GPU stayed 100 % busy for good (the same step, same process, with
+    // a normal-priority stream or on one stream completes).  A step that cannot hang is worth the microseconds.
+    const char *pe = getenv("MSM_AMD_STREAM_B_PRIORITY");
+    if (pe && !strcmp(pe, "high")) HIPCHK(hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, prio_hi));
+    else HIPCHK(hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&h->ev_pairs));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
@@ -1304,17 +1325,47 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
     HIPCHK(hipSetDevice(h->device));
     int rc;
     // Two streams: the exchange of the grid charges (and, in halo mode, the first restriction and the all-gather of
-    // the level-1 charges) travels on the second one while the first computes the pair sum, which needs nothing from
-    // the other ranks.  Kernels gain nothing from running side by side here (the pair kernel fills the chip), a
-    // collective in flight does.
-    const bool two = h->opt_slab_overlap != 0 && slab;
+    // the level-1 charges) travels on the second one while the first builds the lists and computes the pair sum, which
+    // need nothing from the other ranks.  What else follows the exchange on the second stream is opt_slab_overlap's:
+    // small, latency-bound kernels pay there (the chain of the coarser levels; on a thin slab the whole grid stage),
+    // large ones compete with the pair kernel for the FP64 pipe and do not.
+    const int ov = h->opt_slab_overlap >= 0 ? h->opt_slab_overlap : (8L * d.nzplanes <= d.M[2] ? 3 : 2);
+    const bool two = ov != 0 && slab;
     if (two && (rc = ensure_stream_b(h))) return rc;
     h->pk_recorded = false;
+    // A handle on the default stream runs the two-stream step on streams of its own, ordered behind the default stream's
+    // work at the start and ahead of its later work at the end.  The default stream synchronises implicitly with every
+    // blocking stream of the process: with a communication library loaded and more streams alive than hardware queues
+    // (4 on this platform), waits of the default stream on the second stream in the middle of a step were seen never to
+    // return.  Between non-blocking streams the only dependencies are the events of this function.
+    struct DefaultStreamGuard {
+        msm_amd_handle *h;
+        hipStream_t user;
+        bool on;
+        ~DefaultStreamGuard() {
+            if (!on) return;
+            if (hipEventRecord(h->ev_out, h->stream_a) == hipSuccess) (void)hipStreamWaitEvent(user, h->ev_out, 0);
+            h->stream = user;
+        }
+    } guard{h, h->stream, false};
+    if (two && h->stream == nullptr && h->opt_slab_own_stream) {
+        if (!h->stream_a) {
+            HIPCHK(hipStreamCreateWithFlags(&h->stream_a, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(h->ev_in, h->stream));
+        HIPCHK(hipStreamWaitEvent(h->stream_a, h->ev_in, 0));
+        h->stream = h->stream_a;
+        guard.on = true;
+    }
     hipStream_t a = h->stream, b = two ? h->stream_b : h->stream;
     const size_t plane = (size_t)d.M[0] * d.M[1];
     bool coarse_on_b = false;
+    // 3: the whole grid stage behind the exchange on the second stream, 4: and the anterpolation before it (A/B)
+    const bool grid_on_b = two && ov >= 3 && !h->profiling, anterp_on_b = grid_on_b && ov == 4;
     if ((rc = msm_amd_stage_bin(h, d_r, d_q))) return rc;
-    if ((rc = msm_amd_stage_anterpolate(h))) return rc;
+    if (!anterp_on_b && (rc = msm_amd_stage_anterpolate(h))) return rc;
     if (two) {
         HIPCHK(hipEventRecord(h->ev_fork, a));
         HIPCHK(hipStreamWaitEvent(b, h->ev_fork, 0));
@@ -1322,8 +1373,9 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
     if (slab) {
         h->stream = b; // the helpers enqueue on the handle's stream
         double *q0 = h->gq[0];
-        rc = 0;
-        if (xmode == MSM_AMD_SLAB_REDUCE) {
+        rc = anterp_on_b ? msm_amd_stage_anterpolate(h) : 0;
+        if (rc) {
+        } else if (xmode == MSM_AMD_SLAB_REDUCE) {
             // slabs of different thickness: clear what this rank does not own, then sum over the ranks
             const size_t below = plane * d.zplane0, above = plane * (d.M[2] - d.zplane0 - d.nzplanes);
             if ((below && hipMemsetAsync(q0, 0, below * sizeof(double), b) != hipSuccess) ||
@@ -1353,15 +1405,16 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
         // 2: the chain of the coarser levels (restrictions, their convolutions, top level, prolongations down to level 1:
         // small kernels that each last as long as a launch) follows the exchange on the second stream, beside the pair
         // sum; the first stream is left with the level-0 convolution and the last prolongation
-        coarse_on_b = two && h->opt_slab_overlap == 2 && d.L >= 2 && !h->profiling;
-        if (!rc && coarse_on_b) rc = grid_stage(h, xmode == MSM_AMD_SLAB_HALO, 1);
+        coarse_on_b = two && ov == 2 && d.L >= 2 && !h->profiling;
+        if (!rc && grid_on_b) rc = grid_stage(h, xmode == MSM_AMD_SLAB_HALO, 0);
+        else if (!rc && coarse_on_b) rc = grid_stage(h, xmode == MSM_AMD_SLAB_HALO, 1);
         if (!rc && two && hipEventRecord(h->ev_join, b) != hipSuccess) { set_error("slab step: hipEventRecord failed"); rc = MSM_AMD_EHIP; }
         h->stream = a;
         if (rc) return rc;
     }
     if ((rc = msm_amd_stage_pairs(h, d_acc))) return rc;
     if (two) HIPCHK(hipStreamWaitEvent(a, h->ev_join, 0));
-    if ((rc = grid_stage(h, slab && xmode == MSM_AMD_SLAB_HALO, coarse_on_b ? 2 : 0))) return rc;
+    if (!(slab && grid_on_b) && (rc = grid_stage(h, slab && xmode == MSM_AMD_SLAB_HALO, coarse_on_b ? 2 : 0))) return rc;
     if ((rc = msm_amd_stage_interpolate(h, d_acc))) return rc;
     if ((rc = queue_energies(h, true))) return rc;
     if (coll && world > 1 && coll->all_reduce_sum(coll->ctx, h->d_energies, 5, (void *)a)) {

@@ -368,15 +368,16 @@ def _one_rank_steps(rank, world, options, steps=3):
 
 @pytest.mark.parametrize("rank", [0, 2])
 def test_slab_step_options_keep_the_bits(rank):
-    """The slab step with the coarse-level chain on the exchange stream (slab_overlap 2, the default), with the exchange
-    alone there (1) and on one stream (0); the slab convolution in tiles of 6 to 12 planes; the pair kernel in workgroups
+    """The slab step with the exchange alone on the second stream (slab_overlap 1), with the coarse-level chain behind it
+    (2), the whole grid stage (3), the anterpolation too (4), and on one stream (0); the slab convolution in tiles of 6 to 12 planes; the pair kernel in workgroups
     of 1, 2 and 4 waves: the same kernels on the same data, so accelerations and raw sums agree bit for bit.  Rank 0 owns
     planes whose halo wraps around the period (one plane range for the convolution), rank 2 does not."""
     import torch
     world = 4
     ref_acc, ref_sums = _one_rank_steps(rank, world, {})
     assert torch.isfinite(ref_acc).all() and float(ref_acc.abs().max()) > 0
-    cases = [{"slab_overlap": 0}, {"slab_overlap": 1}, {"conv_tile_planes": 6}, {"conv_tile_planes": 8}, {"conv_tile_planes": 9},
+    cases = [{"slab_overlap": 0}, {"slab_overlap": 1}, {"slab_overlap": 2}, {"slab_overlap": 3}, {"slab_overlap": 4},
+             {"conv_tile_planes": 6}, {"conv_tile_planes": 8}, {"conv_tile_planes": 9},
              {"conv_tile_planes": 10}, {"conv_tile_planes": 12, "slab_overlap": 1}, {"pair_wpb": 2}, {"pair_wpb": 4},
              {"list_wpb": 1}, {"pair_lds_pad": 17408}]
     for opts in cases:
