@@ -1,5 +1,5 @@
 #!/bin/bash
-# The rank table of the design notes: the work of one rank of 1, 2, 4, 8 at 1M and at 10M particles (collectives as no-ops)
+# The work of one rank of 1, 2, 4, 8 at 1M and at 10M particles on one GPU (collectives as no-ops), as one table
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/final
 mkdir -p $O
