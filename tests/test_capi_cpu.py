@@ -172,6 +172,8 @@ def test_no_cpu_fallback(msm):
     assert lib.msm_amd_slab_step(None, None, None, None, None, 0) == -1 and b"null argument" in lib.msm_amd_last_error()
     assert lib.msm_amd_slab_exchange_mode(None, 8, 0) < 0
     assert lib.msm_amd_slab_energies(None, None, (C.c_double * 16)()) == -1
+    # the profiling hook of the pair kernel refuses a null handle as well
+    assert lib.msm_amd_set_pair_trace(None, None) == -1 and lib.msm_amd_pair_trace_slots(None) == 0
     ident = C.create_string_buffer(128)
     if lib.msm_amd_rccl_unique_id(ident) == 0:   # librccl is present in the image
         from msm_amd.capi import Collectives
