@@ -347,17 +347,23 @@ class _NoDist:
         return "nccl"
 
 
-def _one_rank_steps(rank, world, options, steps=3):
+def _one_rank_steps(rank, world, options, steps=3, kind="halo"):
     """`steps` evaluations of one rank of `world` with collectives that move nothing: the planes of the other ranks keep
     what they held, which depends only on the rank's own history, so two runs of the same history give the same bits
     whichever stream or launch shape the engine's options pick."""
     import torch
     import msm_amd
     from msm_amd.slab import SlabRank, NullCollectives
-    N, desc = _plan(msm_amd, ("explicit", 100000, 6, 4, 96, 0.04))
-    r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=47)
+    if kind == "open":      # open boundaries: slabs cut by particle count, level-0 charges summed over the ranks
+        from test_gpu_parity import open_system
+        N, p, mu, hh, a, L = OPEN_SLAB
+        r, q = open_system(N, 5, (1.0, 0.8, 1.3), (0.3, -0.2, 5.0))
+        desc = msm_amd.plan_open(N, r.min(axis=0), r.max(axis=0), p, mu, hh, a, L)
+    else:                   # a = 0.07 on the 96^3 grid: 16 halo planes do not fit a slab of 12, the all-gather it is
+        N, desc = _plan(msm_amd, ("explicit", 100000, 6, 4, 96, 0.04 if kind == "halo" else 0.07))
+        r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=47)
     s = SlabRank(torch, _NoDist(), msm_amd, desc, r, q, rank, world, 0, perturb=False, collectives=NullCollectives(rank, world))
-    assert s.eng.slab_exchange_mode(world, 0) == 2          # halo exchange: the step with the most stages in flight
+    assert s.eng.slab_exchange_mode(world, 0) == {"halo": 2, "allgather": 1, "open": 3}[kind]
     for k, v in options.items():
         s.eng.set_option(k, v)
     for _ in range(steps):
@@ -416,3 +422,17 @@ def test_pair_trace_hook():
     eng.eval(r, q)
     torch.cuda.synchronize()
     assert int(buf.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("kind,world,rank", [("allgather", 8, 0), ("open", 4, 1)])
+def test_slab_step_streams_keep_the_bits_other_exchanges(kind, world, rank):
+    """The same for the two other exchanges of the level-0 charges: the all-gather of the whole grid (8 ranks of the
+    benchmark's grid with a cutoff whose halo does not fit a slab) and the sum over the ranks of an open-boundary plan."""
+    import torch
+    ref_acc, ref_sums = _one_rank_steps(rank, world, {}, kind=kind)
+    assert torch.isfinite(ref_acc).all() and float(ref_acc.abs().max()) > 0
+    for opts in ({"slab_overlap": 0}, {"slab_overlap": 1}, {"slab_overlap": 2}, {"slab_overlap": 3}, {"slab_overlap": 4},
+                 {"conv_tile_planes": 8}, {"pair_wpb": 4}):
+        acc, sums = _one_rank_steps(rank, world, opts, kind=kind)
+        assert torch.equal(acc, ref_acc), (kind, opts)
+        assert torch.equal(sums, ref_sums), (kind, opts)
