@@ -1996,6 +1996,28 @@ bool launch_conv_multi(hipStream_t st, ConvBatch &B) {
         }
         if (B.c[0].ks[2] == 15 && B.sym && conv_split_launch<15, 4, 5, true>(st, B)) return true;
         if (B.c[0].ks[2] == 15 && conv_split_launch<15, 4, 5>(st, B)) return true;
+        if (B.c[0].ks[2] == 19 && B.sym == 2) {
+            // A thick slab of a large grid (10M particles: 38 planes of 256 x 256 nodes on a rank of 8) has tiles enough
+            // to fill the chip with the whole-grid kernel, which needs half the time per plane (16+ outputs per thread:
+            // half the window reads per multiplication) but comes in tiles of 32 planes: 38 planes would cost 64.  With
+            // 17, 18 or 19 outputs per thread a tile is 34, 36 or 38 planes tall (the LDS holds up to 38 + 18 planes of
+            // 34 x 10 doubles), and the height that wastes the fewest planes is taken: 38 for 38, 36 for the 70 planes
+            // of a rank of 4, 34 for the 134 of a rank of 2.
+            const int nz = B.c[0].nz;
+            const long per_layer = (long)((B.c[0].M[0] + 15) / 16) * ((B.c[0].M[1] + 7) / 8);
+            int pick = 0;
+            long best = 2L * 8 * ((nz + 7) / 8); // the split kernel: tiles of 8 planes at twice the time per plane
+            for (int r = 16; r <= 19; r++) {
+                const long layers = (nz + 2 * r - 1) / (2 * r);
+                if ((per_layer * layers >= 256 || B.tile_planes == r) && 2 * r * layers < best) { best = 2 * r * layers; pick = r; }
+            }
+            if (B.tile_planes >= 16 && B.tile_planes <= 19) pick = B.tile_planes; // A/B
+            if (B.tile_planes == 8) pick = 0;
+            if (pick == 16 && conv_multi_launch<19, 16, 16, 8, 32, 3, true>(st, B)) return true;
+            if (pick == 17 && conv_multi_launch<19, 17, 16, 8, 34, 3, true>(st, B)) return true;
+            if (pick == 18 && conv_multi_launch<19, 18, 16, 8, 36, 3, true>(st, B)) return true;
+            if (pick == 19 && conv_multi_launch<19, 19, 16, 8, 38, 3, true>(st, B)) return true;
+        }
         if (B.c[0].ks[2] == 19 && B.sym && conv_split_launch<19, 4, 3, true>(st, B)) return true;
         if (B.c[0].ks[2] == 19 && conv_split_launch<19, 4, 3>(st, B)) return true;
     }

@@ -175,7 +175,7 @@ struct ConvBatch {
     int n;
     int split = 0;       // a slab of planes on level 0: tiles of 8 planes whose stencil columns are shared out over wave groups
     int sym = 0;         // in: the caller allows the mirror symmetry of the stencils along x to be used (sums in another order)
-    int tile_planes = 0; // in: planes per tile of the slab kernel (6, 8, 9, 10, 12; 0: chosen from the number of workgroups)
+    int tile_planes = 0; // in: planes per tile of the slab kernel (15 taps: 6, 8, 9, 10, 12; 19 taps: 8, or 16 to 19 outputs per thread of the whole-grid kernel; 0: chosen per launch)
     int blk0[9];
     int ntx[8], nty[8];
     ConvArgs c[8];

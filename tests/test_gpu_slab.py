@@ -360,10 +360,10 @@ def _one_rank_steps(rank, world, options, steps=3, kind="halo"):
         r, q = open_system(N, 5, (1.0, 0.8, 1.3), (0.3, -0.2, 5.0))
         desc = msm_amd.plan_open(N, r.min(axis=0), r.max(axis=0), p, mu, hh, a, L)
     else:                   # a = 0.07 on the 96^3 grid: 16 halo planes do not fit a slab of 12, the all-gather it is
-        N, desc = _plan(msm_amd, ("explicit", 100000, 6, 4, 96, 0.04 if kind == "halo" else 0.07))
+        N, desc = _plan(msm_amd, ("explicit", 100000, 6, 4, 96, {"halo": 0.04, "wide": 5.0 / 96, "allgather": 0.07}[kind]))
         r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=47)
     s = SlabRank(torch, _NoDist(), msm_amd, desc, r, q, rank, world, 0, perturb=False, collectives=NullCollectives(rank, world))
-    assert s.eng.slab_exchange_mode(world, 0) == {"halo": 2, "allgather": 1, "open": 3}[kind]
+    assert s.eng.slab_exchange_mode(world, 0) == {"halo": 2, "wide": 2, "allgather": 1, "open": 3}[kind]
     for k, v in options.items():
         s.eng.set_option(k, v)
     for _ in range(steps):
@@ -436,3 +436,19 @@ def test_slab_step_streams_keep_the_bits_other_exchanges(kind, world, rank):
         acc, sums = _one_rank_steps(rank, world, opts, kind=kind)
         assert torch.equal(acc, ref_acc), (kind, opts)
         assert torch.equal(sums, ref_sums), (kind, opts)
+
+
+def test_slab_convolution_of_19_taps_in_tall_tiles():
+    """Stencils of 19 taps (a = 5 h) on a slab: the split kernel in tiles of 8 planes (what a grid of this size gets) and
+    the whole-grid kernel with 16 to 19 outputs per thread in tiles of 32 to 38 planes (what a thick slab of a large grid
+    gets; forced here) add their taps in different orders: equal to rounding."""
+    import torch
+    ref_acc, ref_sums = _one_rank_steps(1, 4, {"conv_tile_planes": 8}, kind="wide")
+    scale = float(ref_acc.abs().max())
+    assert scale > 0
+    for planes in (0, 16, 17, 18, 19):
+        acc, sums = _one_rank_steps(1, 4, {"conv_tile_planes": planes}, kind="wide")
+        assert float((acc - ref_acc).abs().max()) <= 1e-12 * scale, planes
+        assert float(((sums - ref_sums).abs() / ref_sums.abs().clamp_min(1e-300)).max()) <= 1e-11, planes
+        if planes == 0:
+            assert torch.equal(acc, ref_acc)      # a grid of 96 x 96 nodes has too few tiles for the tall ones
