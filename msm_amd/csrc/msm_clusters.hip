@@ -127,11 +127,13 @@ __global__ void k_cl_bbox(ClusterGeom g, ClusterBuffers b) {
     const int nin = min(CL_G, ncolp - CL_G * (k - b.clstart[col]));
     double4 *p = b.ps + (size_t)CL_G * k;
     double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+    bool all_owned = true;
     for (int m = 0; m < nin; m++) {
         const double4 v = p[m];
         l[0] = fmin(l[0], v.x); h[0] = fmax(h[0], v.x);
         l[1] = fmin(l[1], v.y); h[1] = fmax(h[1], v.y);
         l[2] = fmin(l[2], v.z); h[2] = fmax(h[2], v.z);
+        all_owned = all_owned && b.order[(size_t)CL_G * k + m] < g.n_owned;
     }
     for (int m = nin; m < CL_G; m++) {
         p[m] = make_double4(g.far, g.far, g.far, 0.0);
@@ -139,7 +141,7 @@ __global__ void k_cl_bbox(ClusterGeom g, ClusterBuffers b) {
     }
     b.blo[k] = make_double4(l[0], l[1], l[2], 0.0);
     b.bhi[k] = make_double4(h[0], h[1], h[2], 0.0);
-    b.fbox[2 * (size_t)k] = make_float4(__double2float_rd(l[0]), __double2float_rd(l[1]), __double2float_rd(l[2]), 0.f);
+    b.fbox[2 * (size_t)k] = make_float4(__double2float_rd(l[0]), __double2float_rd(l[1]), __double2float_rd(l[2]), all_owned ? 1.f : 0.f);
     b.fbox[2 * (size_t)k + 1] = make_float4(__double2float_ru(h[0]), __double2float_ru(h[1]), __double2float_ru(h[2]), 0.f);
 }
 
@@ -390,16 +392,18 @@ __global__ __launch_bounds__(256) void k_cs_colsort(ClusterGeom g, ClusterBuffer
         const int nin = min(CL_G, n - CL_G * k);
         const double4 *p = b.ps + (size_t)CL_G * (c0 + k);
         double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+        bool all_owned = true;
         for (int m = 0; m < nin; m++) {
             const double4 v = p[m];
             l[0] = fmin(l[0], v.x); h[0] = fmax(h[0], v.x);
             l[1] = fmin(l[1], v.y); h[1] = fmax(h[1], v.y);
             l[2] = fmin(l[2], v.z); h[2] = fmax(h[2], v.z);
+            all_owned = all_owned && b.order[(size_t)CL_G * (c0 + k) + m] < g.n_owned;
         }
         const int kk = c0 + k;
         b.blo[kk] = make_double4(l[0], l[1], l[2], 0.0);
         b.bhi[kk] = make_double4(h[0], h[1], h[2], 0.0);
-        b.fbox[2 * (size_t)kk] = make_float4(__double2float_rd(l[0]), __double2float_rd(l[1]), __double2float_rd(l[2]), 0.f);
+        b.fbox[2 * (size_t)kk] = make_float4(__double2float_rd(l[0]), __double2float_rd(l[1]), __double2float_rd(l[2]), all_owned ? 1.f : 0.f);
         b.fbox[2 * (size_t)kk + 1] = make_float4(__double2float_ru(h[0]), __double2float_ru(h[1]), __double2float_ru(h[2]), 0.f);
     }
 }
@@ -504,7 +508,8 @@ __device__ __forceinline__ void cl_ranges(const ClusterGeom &g, const int *__res
     c.n0 = nn[0]; c.n1 = nn[1]; c.n2 = nn[2];
 }
 
-// Calls emit(keep, jcl, code) with all 64 lanes converged; each lane brings its own candidate.
+// Calls emit(keep, jcl, code, jfull) with all 64 lanes converged; each lane brings its own candidate (jfull: every
+// particle of cluster j is owned).
 template <class Emit>
 __device__ __forceinline__ void cl_enumerate(const ClusterGeom &g, const ClusterBuffers &b, double a, double a2, const IBox &ib,
                                              int lane, Emit &&emit) {
@@ -531,7 +536,7 @@ __device__ __forceinline__ void cl_enumerate(const ClusterGeom &g, const Cluster
         for (int t = sub; __ballot(t < total); t += nsub) {
             const bool live = t < total;
             int jcl = 0, code = CL_NOSHIFT;
-            bool keep = false;
+            bool keep = false, jfull = false;
             if (live) {
                 const int seg = (t >= c.n0) + (t >= c.n0 + c.n1);
                 jcl = seg == 0 ? c.b0 + t : (seg == 1 ? c.b1 + (t - c.n0) : c.b2 + (t - c.n0 - c.n1));
@@ -545,8 +550,9 @@ __device__ __forceinline__ void cl_enumerate(const ClusterGeom &g, const Cluster
                 const float gy = fmaxf(0.f, fmaxf(jl.y - c.ihy, c.ily - jh.y));
                 const float gz = fmaxf(0.f, fmaxf(jl.z - (ihz - szf), (ilz - szf) - jh.z));
                 keep = gx * gx + gy * gy + gz * gz < g.a2_wide;
+                jfull = jl.w != 0.f;
             }
-            emit(keep, jcl, code);
+            emit(keep, jcl, code, jfull);
         }
     }
 }
@@ -565,37 +571,43 @@ __global__ __launch_bounds__(256) void k_cl_list(ClusterGeom g, ClusterBuffers b
     if (icl >= ncl) return;
     // a cluster of halo copies only produces no output: no list needed (the pair kernels skip it the same way)
     if (!__ballot(lane < CL_G && b.order[(size_t)CL_G * icl + lane] < n_owned)) {
-        if (lane == 0) { b.n0[icl] = 0; b.n1[icl] = 0; b.n2[icl] = 0; }
+        if (lane == 0) { b.n0[icl] = 0; b.n1[icl] = 0; b.n2[icl] = 0; b.n3[icl] = 0; }
         return;
     }
     const double4 il = b.blo[icl], ih = b.bhi[icl];
     const IBox ib = {il.x, il.y, il.z, ih.x, ih.y, ih.z};
     const int S = g.list_stride, MID = S / 2;
     int *__restrict__ L = b.list + (size_t)icl * S;
-    int nu = 1, nd = 0, ns = 0; // "up" (j > i, from the front, after the cluster itself), "down" (j < i, from the
-                                // middle), shifted (from the back)
+    // "up" (j > i, from the front, after the cluster itself) and "down" (j < i, from the middle): unshifted neighbours
+    // whose particles are all owned; "other": unshifted neighbours with halo copies among their particles (down from
+    // just below the middle; none without a slab decomposition); shifted (from the back)
+    int nu = 1, nd = 0, ns = 0, no = 0;
     bool overflow = false;
     if (lane == 0) L[0] = icl;
-    cl_enumerate(g, b, a, a2, ib, lane, [&](bool keep, int jcl, int code) {
+    cl_enumerate(g, b, a, a2, ib, lane, [&](bool keep, int jcl, int code, bool jfull) {
         if (jcl == icl && code == CL_NOSHIFT) keep = false;
-        const bool ku = keep && code == CL_NOSHIFT && jcl > icl, kd = keep && code == CL_NOSHIFT && jcl < icl;
+        const bool kn = keep && code == CL_NOSHIFT;
+        const bool ku = kn && jfull && jcl > icl, kd = kn && jfull && jcl < icl, ko = kn && !jfull;
         const bool ks = keep && code != CL_NOSHIFT;
-        const unsigned long long mu = __ballot(ku), md = __ballot(kd), ms = __ballot(ks);
-        const int cu = __popcll(mu), cd = __popcll(md), cs = __popcll(ms);
-        if (nu + cu > MID || MID + nd + cd + ns + cs > S) overflow = true;
+        const unsigned long long mu = __ballot(ku), md = __ballot(kd), ms = __ballot(ks), mo = __ballot(ko);
+        const int cu = __popcll(mu), cd = __popcll(md), cs = __popcll(ms), co = __popcll(mo);
+        if (nu + cu + no + co > MID || MID + nd + cd + ns + cs > S) overflow = true;
         else {
             if (ku) L[nu + lane_rank(mu)] = jcl;
             if (kd) L[MID + nd + lane_rank(md)] = jcl;
+            if (ko) L[MID - 1 - (no + lane_rank(mo))] = jcl;
             if (ks) L[S - 1 - (ns + lane_rank(ms))] = (int)((unsigned)jcl | ((unsigned)code << CL_CODE_SHIFT));
         }
         nu += cu;
         nd += cd;
         ns += cs;
+        no += co;
     });
     if (lane == 0) {
         b.n0[icl] = overflow ? -1 : nu;
         b.n1[icl] = ns;
         b.n2[icl] = nd;
+        b.n3[icl] = no;
     }
 }
 
@@ -768,6 +780,10 @@ __global__ __launch_bounds__(256) void k_pair_clusters(ClusterGeom g, ClusterBuf
         if (HALF) cl_slot_force<P>(I.x, I.y, I.z, q, pp, fx, fy, fz);
         else cl_slot<P, false>(I.x, I.y, I.z, q, pp, true, uh, fx, fy, fz);
     }
+    if (!HALF) { // neighbours with halo copies among their particles (a slab rank only)
+        const int no = b.n3[icl];
+        for (e = 0; e < no; e++) cl_slot<P, false>(I.x, I.y, I.z, pj[(size_t)CL_G * L[MID - 1 - e]], pp, true, uh, fx, fy, fz);
+    }
     for (e = 0; e < ns; e++) {
         const int ent = L[S - 1 - e];
         double sx, sy, sz;
@@ -937,9 +953,16 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_pair_clusters_filtered(Cluste
         }
         drain(force_only, ua, true);
     };
-    walk(L + 1, 1, nu - 1, false, No{}, HALF ? u1 : uh);
-    if (HALF) walk(L + MID, 1, nd, false, Yes{}, uh);
+    // A slab rank (not HALF) keeps the one-sided bookkeeping for the cluster pairs that are all its own: a cluster whose
+    // particles are all owned takes the pairs with such clusters after it whole and those with such clusters before it
+    // not at all (forces only), as on one GPU; pairs with a cluster that holds halo copies count half from here (the
+    // owner of the copies, or that cluster's own wave, brings the other half), and so does everything of a cluster with
+    // halo copies among its own particles.
+    const bool ifull = HALF || __builtin_amdgcn_readfirstlane((int)(b.fbox[2 * (size_t)icl].w != 0.f));
+    walk(L + 1, 1, nu - 1, false, No{}, ifull ? u1 : uh);
+    if (ifull) walk(L + MID, 1, nd, false, Yes{}, uh);
     else walk(L + MID, 1, nd, false, No{}, uh);
+    if (!HALF) walk(L + MID - 1, -1, b.n3[icl], false, No{}, uh);
     walk(L + S - 1, -1, ns, true, No{}, uh);
     cl_finish(I, pp, jj, icl, 2.0 * u1 + uh, fx, fy, fz, acc, epart, lane);
     trace(3);
@@ -1111,6 +1134,7 @@ __global__ __launch_bounds__(256, 4) void k_pair_clusters_split(ClusterGeom g, C
     walk(L + 1, 1, nu - 1, false, No{}, HALF ? u1A : uhA, HALF ? u1B : uhB);
     if (HALF) walk(L + MID, 1, nd, false, Yes{}, uhA, uhB);
     else walk(L + MID, 1, nd, false, No{}, uhA, uhB);
+    if (!HALF) walk(L + MID - 1, -1, b.n3[icl], false, No{}, uhA, uhB); // neighbours with halo copies (a slab rank only)
     walk(L + S - 1, -1, ns, true, No{}, uhA, uhB);
 
     // sum the CLS_W lanes that share a particle i, write its acceleration and energy share
@@ -1142,7 +1166,7 @@ __global__ __launch_bounds__(256, 4) void k_pair_clusters_split(ClusterGeom g, C
 template <int P>
 __device__ __forceinline__ void direct_one_cluster(const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double a,
                                                    double *__restrict__ acc, double *__restrict__ epart, int icl, int lane,
-                                                   bool half) {
+                                                   bool half, bool onesided = false) {
     const int ii = lane >> 3, jj = lane & 7;
     const LaneI I = load_lane_i(g, b, pp, icl, ii);
     if (!__ballot(I.owned)) {
@@ -1154,17 +1178,22 @@ __device__ __forceinline__ void direct_one_cluster(const ClusterGeom &g, const C
     const double4 *__restrict__ pj = b.ps + jj;
     // energy bookkeeping as in k_pair_clusters: with `half`, an unshifted pair counts whole on the side whose own
     // cluster comes first, and not at all on the other side
+    // onesided (a slab rank whose other clusters are evaluated by k_pair_clusters_filtered): the same for the pairs of
+    // two clusters whose particles are all owned, half for the others
     double u1 = 0, uh = 0, unone = 0, fx = 0, fy = 0, fz = 0;
-    cl_enumerate(g, b, a, pp.a2, ib, lane, [&](bool keep, int jcl, int code) {
+    const bool ifull = onesided && b.fbox[2 * (size_t)icl].w != 0.f;
+    cl_enumerate(g, b, a, pp.a2, ib, lane, [&](bool keep, int jcl, int code, bool jfull_lane) {
+        const int jfull_bits = (int)jfull_lane;
         unsigned long long m = __ballot(keep);
         while (m) {
             const int l = __ffsll((long long)m) - 1;
             m &= m - 1;
             const int j = __builtin_amdgcn_readlane(jcl, l), cd = __builtin_amdgcn_readlane(code, l);
+            const bool one = half || (ifull && __builtin_amdgcn_readlane(jfull_bits, l) != 0);
             const double4 q = pj[(size_t)CL_G * j];
             if (cd == CL_NOSHIFT) {
                 if (j == icl) cl_slot<P, true>(I.x, I.y, I.z, q, pp, ii != jj, uh, fx, fy, fz);
-                else cl_slot<P, false>(I.x, I.y, I.z, q, pp, true, !half ? uh : (j > icl ? u1 : unone), fx, fy, fz);
+                else cl_slot<P, false>(I.x, I.y, I.z, q, pp, true, !one ? uh : (j > icl ? u1 : unone), fx, fy, fz);
             } else {
                 double sx, sy, sz;
                 shift_of_code(g, cd, sx, sy, sz);
@@ -1195,7 +1224,7 @@ __global__ __launch_bounds__(256) void k_pair_clusters_direct(ClusterGeom g, Clu
 template <int P>
 __global__ __launch_bounds__(256) void k_pair_clusters_overflow(ClusterGeom g, ClusterBuffers b, PairParams pp, double a,
                                                                 double *__restrict__ acc, double *__restrict__ epart,
-                                                                int half) {
+                                                                int half, int onesided) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const int ncl = b.clstart[g.ncols];
@@ -1204,7 +1233,7 @@ __global__ __launch_bounds__(256) void k_pair_clusters_overflow(ClusterGeom g, C
         while (m) {
             const int l = __ffsll((long long)m) - 1;
             m &= m - 1;
-            direct_one_cluster<P>(g, b, pp, a, acc, epart, base + l, lane, half != 0);
+            direct_one_cluster<P>(g, b, pp, a, acc, epart, base + l, lane, half != 0, onesided != 0);
         }
     }
 }
@@ -1233,12 +1262,14 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
         if (ev) hipEventRecord(ev[1], st);                                                                     \
     } while (0)
     const bool h = half && variant != 2; // variant 2: every pair counted half from both sides (A/B)
+    // a slab rank's list-free kernel books the pair energies as the kernel that walks the other clusters' lists does
+    const int onesided = (!half && variant == 3 && g.max_clusters < (1 << 24)) ? 1 : 0;
 #define LAUNCH_PF(P, HALF)                                                                                          \
     do {                                                                                                            \
         if (ev) hipEventRecord(ev[0], st);                                                                          \
         if (max_wgs > 0 || wpb == 4) hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF, 1, 4>), dim3(nwg), dim3(256), lds_pad, st, g, b, pp, acc, epart); \
         else if (wpb == 2) hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF, 1, 2>), dim3((g.max_clusters + 1) / 2), dim3(128), lds_pad, st, g, b, pp, acc, epart); \
-        else hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF, 1, 1>), dim3(g.max_clusters), dim3(64), lds_pad, st, g, b, pp, acc, epart); \
+        else hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF, 4, 1>), dim3(g.max_clusters), dim3(64), lds_pad, st, g, b, pp, acc, epart); \
         if (ev) hipEventRecord(ev[1], st);                                                                          \
     } while (0)
     if (variant == 4 && g.max_clusters < (1 << 24)) { // particle granularity, survivors split by the half of i they are near
@@ -1266,9 +1297,9 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
         else LAUNCH_PC(6, false, 4);
     }
     if (pp.p == 4) {
-        hipLaunchKernelGGL((k_pair_clusters_overflow<4>), dim3(std::min(nblk, 2048)), dim3(256), 0, st, g, b, pp, a, acc, epart, h ? 1 : 0);
+        hipLaunchKernelGGL((k_pair_clusters_overflow<4>), dim3(std::min(nblk, 2048)), dim3(256), 0, st, g, b, pp, a, acc, epart, h ? 1 : 0, onesided);
     } else {
-        hipLaunchKernelGGL((k_pair_clusters_overflow<6>), dim3(std::min(nblk, 2048)), dim3(256), 0, st, g, b, pp, a, acc, epart, h ? 1 : 0);
+        hipLaunchKernelGGL((k_pair_clusters_overflow<6>), dim3(std::min(nblk, 2048)), dim3(256), 0, st, g, b, pp, a, acc, epart, h ? 1 : 0, onesided);
     }
 #undef LAUNCH_PC
 #undef LAUNCH_PF

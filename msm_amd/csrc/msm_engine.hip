@@ -345,6 +345,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         cg.dzf = d.A[2] / cg.nzf; cg.inv_dzf = cg.nzf / d.A[2];
         cg.far = -1.0e3 * amax;
         { const double aw = d.a + 4e-6 * amax; cg.a2_wide = (float)(aw * aw * (1.0 + 1e-6)); }
+        cg.n_owned = h->n_owned;
     }
 
 #define DA(ptr, n)                      \
@@ -384,7 +385,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         DA(cb.colncl, cg.ncols + 1); DA(cb.clstart, cg.ncols + 1);
         DA(cb.order, nslots); DA(cb.ps, nslots + CL_G); // + one cluster of inert slots behind the last one
         DA(cb.blo, cg.max_clusters); DA(cb.bhi, cg.max_clusters); DA(cb.fbox, 2 * (size_t)cg.max_clusters);
-        DA(cb.list, (size_t)cg.max_clusters * cg.list_stride); DA(cb.n0, cg.max_clusters); DA(cb.n1, cg.max_clusters); DA(cb.n2, cg.max_clusters);
+        DA(cb.list, (size_t)cg.max_clusters * cg.list_stride); DA(cb.n0, cg.max_clusters); DA(cb.n1, cg.max_clusters); DA(cb.n2, cg.max_clusters); DA(cb.n3, cg.max_clusters);
     }
     h->gq.assign(L, nullptr); h->ge.assign(L, nullptr); h->dK.assign(L, nullptr); h->dKt.assign(L, nullptr);
     h->dKsub.assign(L, nullptr); h->sub_s.assign(L, 0); h->sub_n.assign(L, 0);
@@ -492,7 +493,7 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
         ClusterBuffers &cb = h->clb;
         hipFree(cb.hist); hipFree(cb.coltotal); hipFree(cb.cpstart); hipFree(cb.bps); hipFree(cb.bkey);
         hipFree(cb.count); hipFree(cb.start); hipFree(cb.colncl); hipFree(cb.clstart); hipFree(cb.order);
-        hipFree(cb.ps); hipFree(cb.blo); hipFree(cb.bhi); hipFree(cb.fbox); hipFree(cb.list); hipFree(cb.n0); hipFree(cb.n1); hipFree(cb.n2);
+        hipFree(cb.ps); hipFree(cb.blo); hipFree(cb.bhi); hipFree(cb.fbox); hipFree(cb.list); hipFree(cb.n0); hipFree(cb.n1); hipFree(cb.n2); hipFree(cb.n3);
     }
     for (auto p : h->gq) hipFree(p);
     for (auto p : h->ge) hipFree(p);
@@ -535,6 +536,7 @@ extern "C" int msm_amd_set_counts(msm_amd_handle *h, int n_total, int n_owned) {
     h->n_owned = n_owned;
     h->pp.n_owned = n_owned;
     h->sp.n_owned = n_owned;
+    h->clg.n_owned = n_owned;
     return MSM_AMD_OK;
 }
 

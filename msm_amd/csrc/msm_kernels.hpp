@@ -87,6 +87,7 @@ struct ClusterGeom {
     float a2_wide;       // cutoff^2 widened to cover single-precision rounding in the box tests
     double origin[3];    // corner of the cell (0 for periodic plans): positions enter as r - origin
     int sort_blocks;     // workgroups of the two-level sort (0: the sort with one counter per fine bin is used)
+    int n_owned;         // particles with original index >= n_owned are halo copies (kept equal to PairParams::n_owned)
 };
 struct ClusterBuffers {
     int *count, *start;         // per fine bin (start has nbins + 1 entries)
@@ -94,9 +95,12 @@ struct ClusterBuffers {
     int *order;                 // original particle index per slot, CL_DUMMY for padding
     double4 *ps;                // (x, y, z, q) per slot, absolute coordinates in [0, A)
     double4 *blo, *bhi;         // cluster bounding boxes
-    float4 *fbox;               // the same rounded outwards to single precision: [2k] = low corner, [2k+1] = high corner
-    int *list, *n0, *n1, *n2;   // neighbour-cluster lists: n0 entries (self + later clusters) from the front, n2 (earlier
-                                // clusters) from the middle, n1 (through a periodic image) from the back; n0 < 0: overflow
+    float4 *fbox;               // the same rounded outwards to single precision: [2k] = low corner, [2k+1] = high corner;
+                                // [2k].w = 1 if every particle of the cluster is owned (no halo copy among them), else 0
+    int *list, *n0, *n1, *n2, *n3; // neighbour-cluster lists: n0 entries (self + later clusters) from the front, n2 (earlier
+                                // clusters) from the middle, n1 (through a periodic image) from the back; n0 < 0: overflow.
+                                // The front and the middle hold clusters whose particles are all owned; unshifted neighbours
+                                // with halo copies among their particles (n3 of them) run down from just below the middle.
     // two-level sort: per (workgroup, column) counts / offsets, particles per column and their exclusive scan, and the
     // particles as they land in their column's bucket (any order inside a bucket)
     int *hist, *coltotal, *cpstart;

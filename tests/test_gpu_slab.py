@@ -19,12 +19,24 @@ def _plan(msm_amd, spec):
     if spec[0] == "auto":
         _, N, p, L = spec
         return N, msm_amd.plan_auto(N, A, p, 10, 4.0, L)
-    _, N, p, L, M, a = spec
+    _, N, p, L, M, a = spec      # ("explicit" | "blob", ...)
     lib = msm_amd.load()
     aL, hL = 2.0 ** L * a, 2.0 ** (L - 1) / M
     beta = lib.choosebetaNew(1e-12, aL, hL)
     kmax = int(math.ceil(abs(lib.choosekmax(1e-12, beta, hL))))
     return N, msm_amd.plan_explicit(N, A, (M, M, M), p, 10, L, a, beta, kmax)
+
+
+def _system(N, spec):
+    """Uniform random charges; for a "blob" plan three quarters of them sit in a ball of radius ~0.02 on the face between
+    the slabs of ranks 0 and 1 of two: its clusters, owned, halo copies and mixed, overflow their neighbour lists and go
+    to the list-free kernel, which has to book the pair energies as the list-walking kernel does for the others."""
+    r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=43)
+    if spec[0] == "blob":
+        rng = np.random.default_rng(11)
+        n = 3 * N // 4
+        r[:n] = (0.5 + 0.01 * rng.standard_normal((n, 3))) % 1.0
+    return r, q
 
 
 def _worker(rank, world, port, spec, mode, c_step, out_dir):
@@ -38,7 +50,7 @@ def _worker(rank, world, port, spec, mode, c_step, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     N, desc = _plan(msm_amd, spec)
-    r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=43)
+    r, q = _system(N, spec)
     sr = SlabRank(torch, dist, msm_amd, desc, r, q, rank, world, local_rank=0, perturb=False, mode=mode, c_step=c_step)
     used = sr.eng.slab_exchange_mode(world, mode) if c_step else 0
     for _ in range(2):   # twice: the second step must not see state left by the first
@@ -71,6 +83,8 @@ SLAB_CASES = [
     # a grid that is no multiple of the 8-cell tiles of the spline kernels, three ranks: the middle one visits some layers
     # of tiles only, the outer ones (their halo wraps around the odd last layer) all of them
     (3, ("explicit", 50000, 6, 3, 60, 0.05), 0, True, 2),
+    # a crowded ball on the face between two slabs: list overflow on both ranks (the list-free kernel beside the list-walking one)
+    (2, ("blob", 16000, 4, 2, 32, 0.1), 0, True, 1),
 ]
 
 
@@ -81,7 +95,7 @@ def test_slab_ranks_match_single_gpu(tmp_path, world, spec, mode, c_step, expect
     import msm_amd
     mp.spawn(_worker, args=(world, _free_port(), spec, mode, c_step, str(tmp_path)), nprocs=world, join=True)
     N, desc = _plan(msm_amd, spec)
-    r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=43)
+    r, q = _system(N, spec)
     eng = msm_amd.Engine(desc)
     en1, acc1 = eng.eval(r, q)
     acc1 = acc1.cpu().numpy()
