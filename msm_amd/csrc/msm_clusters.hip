@@ -1269,7 +1269,7 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
         if (ev) hipEventRecord(ev[0], st);                                                                          \
         if (max_wgs > 0 || wpb == 4) hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF, 1, 4>), dim3(nwg), dim3(256), lds_pad, st, g, b, pp, acc, epart); \
         else if (wpb == 2) hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF, 1, 2>), dim3((g.max_clusters + 1) / 2), dim3(128), lds_pad, st, g, b, pp, acc, epart); \
-        else hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF, 4, 1>), dim3(g.max_clusters), dim3(64), lds_pad, st, g, b, pp, acc, epart); \
+        else hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF, (HALF ? 1 : 4), 1>), dim3(g.max_clusters), dim3(64), lds_pad, st, g, b, pp, acc, epart); \
         if (ev) hipEventRecord(ev[1], st);                                                                          \
     } while (0)
     if (variant == 4 && g.max_clusters < (1 << 24)) { // particle granularity, survivors split by the half of i they are near
