@@ -133,7 +133,7 @@ __global__ void k_cl_bbox(ClusterGeom g, ClusterBuffers b) {
         l[0] = fmin(l[0], v.x); h[0] = fmax(h[0], v.x);
         l[1] = fmin(l[1], v.y); h[1] = fmax(h[1], v.y);
         l[2] = fmin(l[2], v.z); h[2] = fmax(h[2], v.z);
-        all_owned = all_owned && b.order[(size_t)CL_G * k + m] < g.n_owned;
+        if (g.n_owned != CL_ALL_OWNED) all_owned = all_owned && b.order[(size_t)CL_G * k + m] < g.n_owned;
     }
     for (int m = nin; m < CL_G; m++) {
         p[m] = make_double4(g.far, g.far, g.far, 0.0);
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void k_cs_colsort(ClusterGeom g, ClusterBuffer
             l[0] = fmin(l[0], v.x); h[0] = fmax(h[0], v.x);
             l[1] = fmin(l[1], v.y); h[1] = fmax(h[1], v.y);
             l[2] = fmin(l[2], v.z); h[2] = fmax(h[2], v.z);
-            all_owned = all_owned && b.order[(size_t)CL_G * (c0 + k) + m] < g.n_owned;
+            if (g.n_owned != CL_ALL_OWNED) all_owned = all_owned && b.order[(size_t)CL_G * (c0 + k) + m] < g.n_owned;
         }
         const int kk = c0 + k;
         b.blo[kk] = make_double4(l[0], l[1], l[2], 0.0);
@@ -564,6 +564,9 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {
 // One wave per cluster: the list of its neighbour clusters.  Entry 0 is the cluster itself; unshifted
 // neighbours follow from the front, neighbours seen through a periodic image are stored from the back with
 // their shift code in the top bits.
+// SLAB: the handle holds halo copies (only then can a neighbour be anything but fully owned; without them the fourth
+// section stays empty and its bookkeeping is left out of the kernel)
+template <bool SLAB>
 __global__ __launch_bounds__(256) void k_cl_list(ClusterGeom g, ClusterBuffers b, double a, double a2, int n_owned) {
     const int lane = threadIdx.x & 63;
     const int icl = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(256) void k_cl_list(ClusterGeom g, ClusterBuffers b
     if (icl >= ncl) return;
     // a cluster of halo copies only produces no output: no list needed (the pair kernels skip it the same way)
     if (!__ballot(lane < CL_G && b.order[(size_t)CL_G * icl + lane] < n_owned)) {
-        if (lane == 0) { b.n0[icl] = 0; b.n1[icl] = 0; b.n2[icl] = 0; b.n3[icl] = 0; }
+        if (lane == 0) { b.n0[icl] = 0; b.n1[icl] = 0; b.n2[icl] = 0; if (SLAB) b.n3[icl] = 0; }
         return;
     }
     const double4 il = b.blo[icl], ih = b.bhi[icl];
@@ -587,15 +590,16 @@ __global__ __launch_bounds__(256) void k_cl_list(ClusterGeom g, ClusterBuffers b
     cl_enumerate(g, b, a, a2, ib, lane, [&](bool keep, int jcl, int code, bool jfull) {
         if (jcl == icl && code == CL_NOSHIFT) keep = false;
         const bool kn = keep && code == CL_NOSHIFT;
-        const bool ku = kn && jfull && jcl > icl, kd = kn && jfull && jcl < icl, ko = kn && !jfull;
+        if (!SLAB) jfull = true;
+        const bool ku = kn && jfull && jcl > icl, kd = kn && jfull && jcl < icl, ko = SLAB && kn && !jfull;
         const bool ks = keep && code != CL_NOSHIFT;
-        const unsigned long long mu = __ballot(ku), md = __ballot(kd), ms = __ballot(ks), mo = __ballot(ko);
-        const int cu = __popcll(mu), cd = __popcll(md), cs = __popcll(ms), co = __popcll(mo);
+        const unsigned long long mu = __ballot(ku), md = __ballot(kd), ms = __ballot(ks), mo = SLAB ? __ballot(ko) : 0ull;
+        const int cu = __popcll(mu), cd = __popcll(md), cs = __popcll(ms), co = SLAB ? __popcll(mo) : 0;
         if (nu + cu + no + co > MID || MID + nd + cd + ns + cs > S) overflow = true;
         else {
             if (ku) L[nu + lane_rank(mu)] = jcl;
             if (kd) L[MID + nd + lane_rank(md)] = jcl;
-            if (ko) L[MID - 1 - (no + lane_rank(mo))] = jcl;
+            if (SLAB && ko) L[MID - 1 - (no + lane_rank(mo))] = jcl;
             if (ks) L[S - 1 - (ns + lane_rank(ms))] = (int)((unsigned)jcl | ((unsigned)code << CL_CODE_SHIFT));
         }
         nu += cu;
@@ -607,7 +611,7 @@ __global__ __launch_bounds__(256) void k_cl_list(ClusterGeom g, ClusterBuffers b
         b.n0[icl] = overflow ? -1 : nu;
         b.n1[icl] = ns;
         b.n2[icl] = nd;
-        b.n3[icl] = no;
+        if (SLAB) b.n3[icl] = no;
     }
 }
 
@@ -1252,8 +1256,16 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
         else hipLaunchKernelGGL((k_pair_clusters_direct<6>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart, half);
         return;
     }
-    if (list_wpb == 1) hipLaunchKernelGGL(k_cl_list, dim3(g.max_clusters), dim3(64), 0, st, g, b, a, pp.a2, pp.n_owned);
-    else hipLaunchKernelGGL(k_cl_list, dim3(nblk), dim3(256), 0, st, g, b, a, pp.a2, pp.n_owned);
+    // the pair kernels that read the fourth list section (every instantiation but the one-sided ones of a handle without
+    // halo copies) need its length written: only those one-sided kernels go with the list build that leaves it out
+    const bool h = half && variant != 2; // variant 2: every pair counted half from both sides (A/B)
+    if (list_wpb == 1) {
+        if (h) hipLaunchKernelGGL(k_cl_list<false>, dim3(g.max_clusters), dim3(64), 0, st, g, b, a, pp.a2, pp.n_owned);
+        else hipLaunchKernelGGL(k_cl_list<true>, dim3(g.max_clusters), dim3(64), 0, st, g, b, a, pp.a2, pp.n_owned);
+    } else {
+        if (h) hipLaunchKernelGGL(k_cl_list<false>, dim3(nblk), dim3(256), 0, st, g, b, a, pp.a2, pp.n_owned);
+        else hipLaunchKernelGGL(k_cl_list<true>, dim3(nblk), dim3(256), 0, st, g, b, a, pp.a2, pp.n_owned);
+    }
     if (after_lists) hipEventRecord(after_lists, st); // lets another stream start beside the pair kernel, not beside the list build
 #define LAUNCH_PC(P, HALF, U)                                                                                  \
     do {                                                                                                       \
@@ -1261,7 +1273,6 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
         hipLaunchKernelGGL((k_pair_clusters<P, HALF, U>), dim3(nblk), dim3(256), 0, st, g, b, pp, acc, epart); \
         if (ev) hipEventRecord(ev[1], st);                                                                     \
     } while (0)
-    const bool h = half && variant != 2; // variant 2: every pair counted half from both sides (A/B)
     // a slab rank's list-free kernel books the pair energies as the kernel that walks the other clusters' lists does
     const int onesided = (!half && variant == 3 && g.max_clusters < (1 << 24)) ? 1 : 0;
 #define LAUNCH_PF(P, HALF)                                                                                          \

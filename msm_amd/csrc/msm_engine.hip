@@ -345,7 +345,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         cg.dzf = d.A[2] / cg.nzf; cg.inv_dzf = cg.nzf / d.A[2];
         cg.far = -1.0e3 * amax;
         { const double aw = d.a + 4e-6 * amax; cg.a2_wide = (float)(aw * aw * (1.0 + 1e-6)); }
-        cg.n_owned = h->n_owned;
+        cg.n_owned = h->n_owned >= h->N ? CL_ALL_OWNED : h->n_owned;
     }
 
 #define DA(ptr, n)                      \
@@ -386,6 +386,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         DA(cb.order, nslots); DA(cb.ps, nslots + CL_G); // + one cluster of inert slots behind the last one
         DA(cb.blo, cg.max_clusters); DA(cb.bhi, cg.max_clusters); DA(cb.fbox, 2 * (size_t)cg.max_clusters);
         DA(cb.list, (size_t)cg.max_clusters * cg.list_stride); DA(cb.n0, cg.max_clusters); DA(cb.n1, cg.max_clusters); DA(cb.n2, cg.max_clusters); DA(cb.n3, cg.max_clusters);
+        HIPCHK_H(hipMemset(cb.n3, 0, sizeof(int) * (size_t)cg.max_clusters)); // (a list build without halo copies does not write it)
     }
     h->gq.assign(L, nullptr); h->ge.assign(L, nullptr); h->dK.assign(L, nullptr); h->dKt.assign(L, nullptr);
     h->dKsub.assign(L, nullptr); h->sub_s.assign(L, 0); h->sub_n.assign(L, 0);
@@ -536,7 +537,7 @@ extern "C" int msm_amd_set_counts(msm_amd_handle *h, int n_total, int n_owned) {
     h->n_owned = n_owned;
     h->pp.n_owned = n_owned;
     h->sp.n_owned = n_owned;
-    h->clg.n_owned = n_owned;
+    h->clg.n_owned = n_owned >= n_total ? CL_ALL_OWNED : n_owned;
     return MSM_AMD_OK;
 }
 

@@ -87,8 +87,9 @@ struct ClusterGeom {
     float a2_wide;       // cutoff^2 widened to cover single-precision rounding in the box tests
     double origin[3];    // corner of the cell (0 for periodic plans): positions enter as r - origin
     int sort_blocks;     // workgroups of the two-level sort (0: the sort with one counter per fine bin is used)
-    int n_owned;         // particles with original index >= n_owned are halo copies (kept equal to PairParams::n_owned)
+    int n_owned;         // particles with original index >= n_owned are halo copies; CL_ALL_OWNED when there are none
 };
+#define CL_ALL_OWNED 0x7fffffff
 struct ClusterBuffers {
     int *count, *start;         // per fine bin (start has nbins + 1 entries)
     int *colncl, *clstart;      // clusters per column and their exclusive scan (ncols + 1; last = cluster count)
