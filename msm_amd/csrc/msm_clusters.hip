@@ -785,7 +785,7 @@ __global__ __launch_bounds__(256) void k_pair_clusters(ClusterGeom g, ClusterBuf
         else cl_slot<P, false>(I.x, I.y, I.z, q, pp, true, uh, fx, fy, fz);
     }
     if (!HALF) { // neighbours with halo copies among their particles (a slab rank only)
-        const int no = b.n3[icl];
+        const int no = min(max(b.n3[icl], 0), MID - 1); // (never beyond the half of the list it shares)
         for (e = 0; e < no; e++) cl_slot<P, false>(I.x, I.y, I.z, pj[(size_t)CL_G * L[MID - 1 - e]], pp, true, uh, fx, fy, fz);
     }
     for (e = 0; e < ns; e++) {
@@ -966,7 +966,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_pair_clusters_filtered(Cluste
     walk(L + 1, 1, nu - 1, false, No{}, ifull ? u1 : uh);
     if (ifull) walk(L + MID, 1, nd, false, Yes{}, uh);
     else walk(L + MID, 1, nd, false, No{}, uh);
-    if (!HALF) walk(L + MID - 1, -1, b.n3[icl], false, No{}, uh);
+    if (!HALF) walk(L + MID - 1, -1, min(max(b.n3[icl], 0), MID - 1), false, No{}, uh); // (never beyond its half of the list)
     walk(L + S - 1, -1, ns, true, No{}, uh);
     cl_finish(I, pp, jj, icl, 2.0 * u1 + uh, fx, fy, fz, acc, epart, lane);
     trace(3);
@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(256, 4) void k_pair_clusters_split(ClusterGeom g, C
     walk(L + 1, 1, nu - 1, false, No{}, HALF ? u1A : uhA, HALF ? u1B : uhB);
     if (HALF) walk(L + MID, 1, nd, false, Yes{}, uhA, uhB);
     else walk(L + MID, 1, nd, false, No{}, uhA, uhB);
-    if (!HALF) walk(L + MID - 1, -1, b.n3[icl], false, No{}, uhA, uhB); // neighbours with halo copies (a slab rank only)
+    if (!HALF) walk(L + MID - 1, -1, min(max(b.n3[icl], 0), MID - 1), false, No{}, uhA, uhB); // neighbours with halo copies (a slab rank only)
     walk(L + S - 1, -1, ns, true, No{}, uhA, uhB);
 
     // sum the CLS_W lanes that share a particle i, write its acceleration and energy share
