@@ -1,5 +1,5 @@
 """Does replaying one evaluation from a HIP graph beat queueing its launches?  (Engine on its own stream; the same
-positions every time.)  python tools/graph_test.py [order]"""
+positions every time.)  python tools/graph_replay.py [order]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
