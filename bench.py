@@ -16,6 +16,12 @@ particles in a periodic unit cube, quintic B-spline (p = 6) unless --order 4, ab
 levels 96 -> 48 -> 24 -> 12 plus the Fourier top level.  N > 1 keeps the total work fixed (strong scaling):
 the same million particles are split into z slabs.
 
+--gpus N > 1 started without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself: the parent, which
+never touches the GPU, runs one child per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set,
+forwards rank 0's JSON line and exits non-zero if any rank did.  Under torch.distributed.run the flag must equal
+WORLD_SIZE.  N ranks need N devices: the run fails otherwise instead of measuring fewer (MSM_AMD_BENCH_BACKEND=gloo is a
+functional rehearsal with ranks sharing devices and is labelled as such in the line).
+
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_pair_clusters_filtered, the short-range pair
 sum): algorithmic flops (ordered in-cutoff pairs x 34 flop at p=4 / 42 at p=6) over that kernel's mean
 duration, measured with a pair of HIP events recorded around it on the stream it runs on.  `traffic` is the
@@ -73,16 +79,24 @@ def main():
     ap.add_argument("--no-accuracy", action="store_true", help="skip the Ewald reference (error of the MSM result)")
     ap.add_argument("--opts", default="", help="engine options for A/B runs, key=value,key=value (msm_amd_set_option)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; they must agree" % (args.gpus, world))
 
     import torch
     import msm_amd
     from msm_amd import capi
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path in msm_amd)")
+    if os.environ.get("MSM_AMD_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks need %d devices, %d visible" % (world, world, torch.cuda.device_count()))
     # MSM_AMD_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices,
     # collectives staged through the host): a functional check, never a measurement
     backend = os.environ.get("MSM_AMD_BENCH_BACKEND", "nccl")
@@ -121,10 +135,23 @@ def main():
         eng.set_option(k, int(v))
 
     exchange = ""
+    multi = None
     if world > 1:
         m = eng.slab_exchange_mode(world)
         exchange = {1: "level-0 charge all-gather", 2: "level-0 charge halo exchange + level-1 all-gather"}.get(m, str(m))
         exchange += " (collectives: %s)" % type(stepper.coll).__name__
+        # what the communicator itself reports (not what the launcher asked for), and what every rank holds
+        rccl_ranks = stepper.coll.comm_info()[0] if hasattr(stepper.coll, "comm_info") else None
+        mine = torch.tensor([stepper.n_own, stepper.n_tot, rccl_ranks if rccl_ranks is not None else -1], dtype=torch.int64,
+                            device=dev if backend == "nccl" else "cpu")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        every = [[int(x) for x in t.cpu()] for t in every]
+        multi = {"rccl_ranks": rccl_ranks if all(e[2] == every[0][2] for e in every) else [e[2] for e in every],
+                 "collectives": type(stepper.coll).__name__, "exchange_mode": exchange,
+                 "per_rank": [{"n_owned": e[0], "n_total": e[1]} for e in every]}
+        if sum(e[0] for e in every) != N:
+            raise SystemExit("bench.py: the ranks own %d particles of %d" % (sum(e[0] for e in every), N))
 
     def barrier():
         if dist is not None:
@@ -155,7 +182,8 @@ def main():
     nprof = max(3, min(10, args.steps))
     acc_ms = stepper.profile(nprof)
 
-    pairs = N * (4.0 * math.pi / 3.0) * abar ** 3 / world   # ordered in-cutoff pairs handled by one rank's launch
+    # ordered in-cutoff pairs handled by one launch (of rank 0): its owned particles x the neighbours within the cutoff
+    pairs = (stepper.n_own if world > 1 else N) * (4.0 * math.pi / 3.0) * abar ** 3
     flops = pairs * FLOP_PER_PAIR[p]
     pair_s = (acc_ms.get("pair_kernel") or acc_ms.get("pairs") or acc_ms.get("total", 0.0)) * 1e-3
     achieved = flops / pair_s / 1e12 if pair_s > 0 else 0.0
@@ -209,12 +237,14 @@ def main():
                        "parallelism": "single GPU" if world == 1 else "z-slabs x%d, %s" % (world, exchange),
                        **({"engine_options": args.opts} if args.opts else {}),
                        **({} if backend == "nccl" else {"rehearsal": "ranks share devices, %s collectives through the host: not a measurement" % backend})},
-            "roofline": {"kernel": "k_pair_clusters_filtered (short-range pair sum)", "bound": "valu_fp64", "achieved": achieved,
+            "roofline": {"kernel": "k_pair_clusters_filtered (short-range pair sum)%s" % (" of rank 0" if world > 1 else ""),
+                         "bound": "valu_fp64", "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                          "traffic": traffic, "kernel_ms": pair_s * 1e3,
                          "note": "FP64 vector FMA bound (the FP64 MFMA peak is the same 78.6 TF); algorithmic flops = "
                                  "N*(4pi/3)*abar^3 ordered pairs x %d flop" % FLOP_PER_PAIR[p]},
             "kernel_ms": acc_ms,
+            **({"multi_gpu": multi} if multi is not None else {}),
             "energies_last_timed_step": dict(zip(capi.U_NAMES, [float(x) for x in energies])) if energies is not None else None,
             "energies_note": "of the last timed step, whose positions are the benchmark system displaced by up to 5e-5; the "
                              "unperturbed system is the one in `parity` and `accuracy`",
@@ -227,6 +257,60 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """Start n ranks of this script (one process per GPU, rendezvous on 127.0.0.1), wait for them, print rank 0's JSON line.
+    Runs in a process that never initialises the GPU (torch.cuda.device_count() does not) and replaces no process image:
+    the ranks are children.  Returns the exit status: 0 only if every rank returned 0 and rank 0 printed its line."""
+    import socket
+    import subprocess
+    import threading
+    import torch
+    have = torch.cuda.device_count()
+    shared = os.environ.get("MSM_AMD_BENCH_BACKEND", "nccl") != "nccl"
+    if have < 1 or (have < n and not shared):
+        print("bench.py: --gpus %d needs %d devices, %d visible (no run with fewer ranks is made in its place)" % (n, n, have),
+              file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for k in range(n):
+        env = dict(os.environ, RANK=str(k), LOCAL_RANK=str(k), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if k == 0 else sys.stderr, text=True))
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout.read().splitlines()), daemon=True)
+    reader.start()
+    status = 0
+    pending = set(range(n))
+    while pending:
+        for k in sorted(pending):
+            rc = procs[k].poll()
+            if rc is None:
+                continue
+            pending.discard(k)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+                print("bench.py: rank %d exited with status %d; stopping the other ranks" % (k, rc), file=sys.stderr)
+                for j in pending:
+                    procs[j].terminate()      # (the exact children started above, by handle)
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    out = [ln for ln in lines if ln.startswith("{")]
+    for ln in lines:
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if status == 0 and not out:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        status = 1
+    if status == 0:
+        print(out[-1])
+    return status
 
 
 def ewald_accuracy(torch, msm_amd, r_all, q_all, A, en_msm, acc_msm, dev):

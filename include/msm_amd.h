@@ -329,6 +329,11 @@ typedef struct msm_amd_collectives {
 int msm_amd_rccl_unique_id(char id[128]);
 int msm_amd_rccl_create(const char id[128], int rank, int world, msm_amd_collectives **out);
 void msm_amd_rccl_destroy(msm_amd_collectives *c);
+/* 0 when librccl.so loads in this process and has every entry the table needs, else MSM_AMD_ENODEV: a probe that every
+ * rank can make (and agree on) before any of them enters the collective msm_amd_rccl_create. */
+int msm_amd_rccl_available(void);
+/* what the communicator behind a table of msm_amd_rccl_create reports: ncclCommCount and ncclCommUserRank */
+int msm_amd_rccl_comm_info(const msm_amd_collectives *c, int *ranks, int *rank);
 
 /* How the level-0 charge planes reach the ranks that need them. */
 enum {

@@ -134,6 +134,8 @@ SIGNATURES = {
     "msm_amd_rccl_unique_id": (C.c_int, [C.c_char_p]),
     "msm_amd_rccl_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.POINTER(Collectives))]),
     "msm_amd_rccl_destroy": (None, [C.POINTER(Collectives)]),
+    "msm_amd_rccl_available": (C.c_int, []),
+    "msm_amd_rccl_comm_info": (C.c_int, [C.POINTER(Collectives), _ip, _ip]),
     "msm_amd_slab_exchange_mode": (C.c_int, [_vp, C.c_int, C.c_int]),
     "msm_amd_slab_step": (C.c_int, [_vp, C.POINTER(Collectives), _vp, _vp, _vp, C.c_int]),
     "msm_amd_slab_energies": (C.c_int, [_vp, C.POINTER(Collectives), _dp]),

@@ -29,6 +29,7 @@ using namespace msm;
 
 enum { T_BIN = 0, T_PAIR, T_ANT, T_RES, T_CONV, T_TOP, T_PRO, T_INT, T_RED, T_TOTAL, T_COUNT };
 static const int NPARTS = 256;
+static const int CONV_SPLIT_MAX = 5; // shares of a tile's taps (conv_part holds the partial sums of all but the first)
 
 struct msm_amd_handle {
     HostPlan hp;
@@ -86,11 +87,12 @@ struct msm_amd_handle {
     SplineOpts sopt; // A/B choices of the tile kernels
     // second stream: the grid pipeline runs beside the list build and the pair kernel
     double *energies_alias = nullptr; // device-visible host slot the energies of the evaluation in flight go to
+    // A handle creates at most two streams, once, both non-blocking and without a priority: stream_b (the second branch
+    // of an evaluation) and stream_a (what a handle on the default stream runs the first branch of a slab step on).
     hipStream_t stream_b = nullptr;
-    hipStream_t stream_a = nullptr; // slab step of a handle on the default stream: the stream its first branch runs on instead
+    hipStream_t stream_a = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    hipStream_t stream_g = nullptr; // coarse-level branch of the grid stage
-    hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr;
+    hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr; // fork / join of the coarse-level branch of the grid stage (on stream_b)
     hipEvent_t pairs_after = nullptr; // set for one msm_amd_stage_pairs call: recorded between the list build and the pair kernel
     int opt_conv_sym = 2;       // tiled convolution: mirror columns of a stencil share their multiplications (2: and 16 outputs per thread; 0: off)
     int opt_transfer_chain = 1; // two prolongations per launch where the grids allow it
@@ -506,14 +508,10 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     hipFree(h->d_energies);
     if (h->h_energies) hipHostFree(h->h_energies);
     hipFree(h->s_r); hipFree(h->s_q); hipFree(h->s_acc); hipFree(h->s_acc2); hipFree(h->conv_part);
-    if (h->stream_g) {
-        hipStreamSynchronize(h->stream_g);
-        hipEventDestroy(h->ev_gfork); hipEventDestroy(h->ev_gjoin);
-        hipStreamDestroy(h->stream_g);
-    }
     if (h->stream_b) {
         hipStreamSynchronize(h->stream_b);
         hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_pairs); hipEventDestroy(h->ev_join);
+        hipEventDestroy(h->ev_gfork); hipEventDestroy(h->ev_gjoin);
         hipStreamDestroy(h->stream_b);
     }
     if (h->stream_a) {
@@ -571,7 +569,11 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "overlap")) { h->opt_overlap = value; return MSM_AMD_OK; }
     if (!strcmp(key, "slab_own_stream")) { h->opt_slab_own_stream = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "slab_overlap")) { h->opt_slab_overlap = value; return MSM_AMD_OK; }
-    if (!strcmp(key, "conv_split")) { h->opt_conv_split = value; return MSM_AMD_OK; }
+    if (!strcmp(key, "conv_split")) { // shares of a level-0 tile's taps: conv_part holds the partial sums of shares 1..4
+        if (value < 0 || value > 5) { set_error("conv_split: 0 (off), 1 (chosen per launch) or 2..5 shares"); return MSM_AMD_EINVAL; }
+        h->opt_conv_split = value;
+        return MSM_AMD_OK;
+    }
     if (!strcmp(key, "conv_tile_planes")) { if (value == 0 || value == 6 || (value >= 8 && value <= 10) || value == 12 || (value >= 16 && value <= 19)) { h->opt_conv_tile_planes = value; return MSM_AMD_OK; } }
     if (!strcmp(key, "pair_lds_pad")) { if (value >= 0 && value <= 48 * 1024) { h->opt_pair_lds_pad = value; return MSM_AMD_OK; } }
     if (!strcmp(key, "pair_wpb")) { if (value == 0 || value == 1 || value == 2 || value == 4) { h->opt_pair_wpb = value; return MSM_AMD_OK; } }
@@ -795,13 +797,13 @@ static void convolve_ranges(msm_amd_handle *h, const std::vector<PlaneRange> &ra
             }
             const long n0 = std::count_if(ranges.begin(), ranges.end(), [](const PlaneRange &r) { return r.l == 0; });
             if (h->opt_conv_split && splittable && tiles0 > 0 && tiles0 < 200 && h->hp.d.nzplanes < h->hp.d.M[2]) {
-                split = h->opt_conv_split > 1 ? h->opt_conv_split : (tiles0 < 100 ? 5 : 3);
+                split = std::min(CONV_SPLIT_MAX, h->opt_conv_split > 1 ? h->opt_conv_split : (tiles0 < 100 ? 5 : 3));
                 while (split > 1 && entries + n0 * (split - 1) > 8) split--;
             }
         }
         const size_t n0grid = (size_t)h->hp.d.M[0] * h->hp.d.M[1] * h->hp.d.M[2];
         if (split > 1 && !h->conv_part) {
-            if (dalloc(&h->conv_part, 4 * n0grid)) { split = 1; (void)hipGetLastError(); }
+            if (dalloc(&h->conv_part, (size_t)(CONV_SPLIT_MAX - 1) * n0grid)) { split = 1; (void)hipGetLastError(); }
         }
         // A range that runs past the last plane comes as two entries, [lo, Mz) and [0, rest): the tiled kernels take it as
         // one, [lo, lo + n) modulo Mz (two entries are two sets of tiles, and the short one fills whole tiles with a few
@@ -903,6 +905,7 @@ static int grid_front(msm_amd_handle *h, const msm_amd_collectives *coll) {
     return MSM_AMD_OK;
 }
 
+static int ensure_stream_b(msm_amd_handle *h);
 // part: 0 the whole stage; 1 only the branch of the coarser levels (restrictions, their convolutions, top level,
 // prolongations down to level 1); 2 only what is left after it (level-0 convolution, last prolongation)
 static int grid_stage(msm_amd_handle *h, bool front_done, int part = 0) {
@@ -975,20 +978,15 @@ static int grid_stage(msm_amd_handle *h, bool front_done, int part = 0) {
         return MSM_AMD_OK;
     }
     if (part == 1) return MSM_AMD_OK; // a one-level plan has no coarse branch
-    const bool two = h->opt_grid_streams && !h->hp.literal && L >= 2;
-    if (two && !h->stream_g) {
-        int prio_lo = 0, prio_hi = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        HIPCHK(hipStreamCreateWithFlags(&h->stream_g, hipStreamNonBlocking)); // (no priority: see ensure_stream_b)
-        (void)prio_hi;
-        HIPCHK(hipEventCreateWithFlags(&h->ev_gfork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&h->ev_gjoin, hipEventDisableTiming));
-    }
+    // (A/B option, off by default: measured slower.)  The branch goes to the handle's second stream, so it is only taken
+    // when the stage itself is not already running there.
+    const bool two = h->opt_grid_streams && !h->hp.literal && L >= 2 && st != h->stream_b;
+    if (two) { int rc = ensure_stream_b(h); if (rc) return rc; }
     mark(h, T_RES);
     if (two) {
         HIPCHK(hipEventRecord(h->ev_gfork, st));
-        HIPCHK(hipStreamWaitEvent(h->stream_g, h->ev_gfork, 0));
-        h->stream = h->stream_g; // the helpers below enqueue on the handle's stream
+        HIPCHK(hipStreamWaitEvent(h->stream_b, h->ev_gfork, 0));
+        h->stream = h->stream_b; // the helpers below enqueue on the handle's stream
     }
     for (int l = front_done ? 1 : 0; l + 1 < L; l++) restrict_level(h, l, h->gq[l], h->gq[l + 1]);
     if (!two) {
@@ -1004,7 +1002,7 @@ static int grid_stage(msm_amd_handle *h, bool front_done, int part = 0) {
     if (!two) mark(h, T_PRO);
     prolong_to_level1(h);
     if (two) {
-        hipError_t e = hipEventRecord(h->ev_gjoin, h->stream_g);
+        hipError_t e = hipEventRecord(h->ev_gjoin, h->stream_b);
         h->stream = st;
         if (e != hipSuccess) { set_error("hipEventRecord failed: %s", hipGetErrorString(e)); return MSM_AMD_EHIP; }
         mark(h, T_CONV);
@@ -1124,22 +1122,21 @@ static bool can_overlap(const msm_amd_handle *h) {
            h->opt_pair_variant >= 5 && h->pp.convention != MSM_AMD_ACC_LITERAL;
 }
 
-// second stream for the grid branch
+// The handle's second stream, created once.  Non-blocking and without a priority, like stream_a: every dependency
+// between the streams of a handle is one of the events of this file, recorded before it is waited for, and no wait in
+// the middle of an evaluation involves the default stream (which synchronises implicitly with every blocking stream of
+// the process, whoever made it).  A stream priority is deliberately not offered: the hardware queues of a priority
+// level come out of a pool of their own, so a priority stream changes which streams of the process share a queue, and
+// a two-stream step with a high-priority second stream was seen to leave the GPU busy for good in a process that also
+// held the streams of a communication library.
 static int ensure_stream_b(msm_amd_handle *h) {
     if (h->stream_b) return MSM_AMD_OK;
-    int prio_lo = 0, prio_hi = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    // No stream priority unless asked for (MSM_AMD_STREAM_B_PRIORITY=high, for A/B runs).  With the highest priority the
-    // short kernels of this stream get their CUs sooner beside the pair kernel (a rank of 8: -7 to -14 us per step, a
-    // rank of 2: -19 to -35 us), but in a process that had initialised RCCL and spawned children before, a step with a
-    // high-priority second stream never finished: the GPU stayed 100 % busy for good (the same step, same process, with
-    // a normal-priority stream or on one stream completes).  A step that cannot hang is worth the microseconds.
-    const char *pe = getenv("MSM_AMD_STREAM_B_PRIORITY");
-    if (pe && !strcmp(pe, "high")) HIPCHK(hipStreamCreateWithPriority(&h->stream_b, hipStreamNonBlocking, prio_hi));
-    else HIPCHK(hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&h->ev_pairs));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_gfork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_gjoin, hipEventDisableTiming));
     return MSM_AMD_OK;
 }
 
@@ -1337,11 +1334,11 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
     const bool two = ov != 0 && slab;
     if (two && (rc = ensure_stream_b(h))) return rc;
     h->pk_recorded = false;
-    // A handle on the default stream runs the two-stream step on streams of its own, ordered behind the default stream's
-    // work at the start and ahead of its later work at the end.  The default stream synchronises implicitly with every
-    // blocking stream of the process: with a communication library loaded and more streams alive than hardware queues
-    // (4 on this platform), waits of the default stream on the second stream in the middle of a step were seen never to
-    // return.  Between non-blocking streams the only dependencies are the events of this function.
+    // A handle on the default stream runs the two-stream step on its own two streams, ordered behind the default stream's
+    // work by one event at the start and ahead of its later work by one event at the end.  The default stream
+    // synchronises implicitly with every blocking stream of the process (the caller's, a communication library's), so a
+    // wait of the default stream in the middle of a step would tie the step to streams this file knows nothing about;
+    // between the handle's non-blocking streams the only dependencies are the events recorded here.
     struct DefaultStreamGuard {
         msm_amd_handle *h;
         hipStream_t user;
@@ -1450,6 +1447,8 @@ struct RcclApi {
     int (*GetUniqueId)(RcclId *) = nullptr;
     int (*CommInitRank)(void **, int, RcclId, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
+    int (*CommUserRank)(void *, int *) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
@@ -1477,6 +1476,7 @@ int rccl_load() {
         if (!api.field) { set_error("librccl.so has no %s", name); dlclose(lib); return MSM_AMD_ENODEV; } \
     } while (0)
     SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+    SYM(CommCount, "ncclCommCount"); SYM(CommUserRank, "ncclCommUserRank");
     SYM(AllGather, "ncclAllGather"); SYM(AllReduce, "ncclAllReduce"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
     SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
@@ -1509,6 +1509,18 @@ int rccl_halo_exchange(void *ctx, const double *send_up, const double *send_down
     return rccl_check(r1 ? r1 : (r2 ? r2 : (r3 ? r3 : (r4 ? r4 : r5))), "ncclSend / ncclRecv (halo exchange)");
 }
 } // namespace
+
+extern "C" int msm_amd_rccl_available(void) { return rccl_load(); }
+
+extern "C" int msm_amd_rccl_comm_info(const msm_amd_collectives *c, int *ranks, int *rank) {
+    if (!c || !c->ctx || c->all_gather != rccl_all_gather) { set_error("msm_amd_rccl_comm_info: not a table made by msm_amd_rccl_create"); return MSM_AMD_EINVAL; }
+    int n = 0, r = 0, rc;
+    if ((rc = rccl_check(g_rccl.CommCount(c->ctx, &n), "ncclCommCount"))) return rc;
+    if ((rc = rccl_check(g_rccl.CommUserRank(c->ctx, &r), "ncclCommUserRank"))) return rc;
+    if (ranks) *ranks = n;
+    if (rank) *rank = r;
+    return MSM_AMD_OK;
+}
 
 extern "C" int msm_amd_rccl_unique_id(char id[128]) {
     if (!id) return MSM_AMD_EINVAL;

@@ -29,27 +29,102 @@ from . import capi
 # collectives for msm_amd_slab_step (struct msm_amd_collectives)
 # ---------------------------------------------------------------------------
 class RcclCollectives:
-    """The library's own RCCL table (msm_amd_rccl_create): collectives queued on the engine's streams.  The 128-byte
-    unique id travels from rank 0 over the torch.distributed group that is already up."""
+    """The library's own RCCL table (msm_amd_rccl_create): collectives queued on the engine's streams.  Made by
+    rccl_table_or_none below, which gets the 128-byte unique id from rank 0 over the torch.distributed group."""
 
-    def __init__(self, torch, dist, rank, world, device):
-        lib = capi.load()
-        idbuf = C.create_string_buffer(128)
-        if rank == 0:
-            capi.check(lib.msm_amd_rccl_unique_id(idbuf), "msm_amd_rccl_unique_id")
-        on_dev = dist.get_backend() == "nccl"
-        t = torch.tensor(list(idbuf.raw), dtype=torch.uint8, device=device if on_dev else "cpu")
-        dist.broadcast(t, 0)
-        raw = bytes(t.cpu().tolist())
-        self._p = C.POINTER(capi.Collectives)()
-        with torch.cuda.device(device):
-            capi.check(lib.msm_amd_rccl_create(raw, rank, world, C.byref(self._p)), "msm_amd_rccl_create")
-        self.ptr = self._p
+    def __init__(self, ptr):
+        self._p = ptr
+        self.ptr = ptr
+
+    def comm_info(self):
+        """(ranks, rank) as the communicator reports them (ncclCommCount, ncclCommUserRank)."""
+        n, r = C.c_int(0), C.c_int(0)
+        capi.check(capi.load().msm_amd_rccl_comm_info(self._p, C.byref(n), C.byref(r)), "msm_amd_rccl_comm_info")
+        return n.value, r.value
 
     def close(self):
         if self._p:
             capi.load().msm_amd_rccl_destroy(self._p)
             self._p = C.POINTER(capi.Collectives)()
+
+
+class _LibRcclApi:
+    """The three library calls rccl_table_or_none makes (tests substitute an object that fails where they want)."""
+
+    def __init__(self, torch, device):
+        self.torch, self.device, self.lib = torch, device, capi.load()
+
+    def available(self):
+        capi.check(self.lib.msm_amd_rccl_available(), "msm_amd_rccl_available")
+
+    def unique_id(self):
+        idbuf = C.create_string_buffer(128)
+        capi.check(self.lib.msm_amd_rccl_unique_id(idbuf), "msm_amd_rccl_unique_id")
+        return idbuf.raw
+
+    def create(self, raw, rank, world):
+        p = C.POINTER(capi.Collectives)()
+        with self.torch.cuda.device(self.device):
+            capi.check(self.lib.msm_amd_rccl_create(raw, rank, world, C.byref(p)), "msm_amd_rccl_create")
+        return RcclCollectives(p)
+
+
+def rccl_table_or_none(torch, dist, rank, world, device, api=None):
+    """The library's RCCL table on every rank, or None on every rank.
+
+    Whatever fails on whichever rank, all ranks run the same sequence of collectives on the torch.distributed group, so
+    that no rank ever waits in one collective while another has moved on to the next:
+
+      1. all-reduce (min) of "librccl.so loads in this process" - before anyone calls into the library;
+      2. broadcast from rank 0 of 129 bytes: a status byte and the unique id (rank 0 always takes part: an id it could not
+         make travels as status 0);
+      3. msm_amd_rccl_create on every rank - itself a collective (ncclCommInitRank): if it fails on some ranks only, the
+         others leave it through RCCL's own timeout;
+      4. all-reduce (min) of "my communicator is up"; a rank that has one and learns that another has not destroys it.
+    """
+    import sys
+    api = api or _LibRcclApi(torch, device)
+    cdev = device if dist.get_backend() == "nccl" else "cpu"
+
+    def all_ok(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    def note(what, e):
+        print("msm_amd.slab: rank %d: %s: %s; collectives through torch.distributed instead" % (rank, what, e), file=sys.stderr)
+
+    ok = True
+    try:
+        api.available()
+    except Exception as e:  # noqa: BLE001 - whatever went wrong, the ranks only need to agree
+        note("librccl", e)
+        ok = False
+    if not all_ok(ok):
+        return None
+    msg = torch.zeros(129, dtype=torch.uint8)
+    if rank == 0:
+        try:
+            raw = api.unique_id()
+            msg[0] = 1
+            msg[1:] = torch.tensor(list(raw), dtype=torch.uint8)
+        except Exception as e:  # noqa: BLE001
+            note("unique id", e)
+    msg = msg.to(cdev)
+    dist.broadcast(msg, 0)
+    msg = msg.cpu()
+    if int(msg[0]) != 1:
+        return None
+    table = None
+    try:
+        table = api.create(bytes(msg[1:].tolist()), rank, world)
+    except Exception as e:  # noqa: BLE001
+        note("communicator", e)
+    if not all_ok(table is not None):
+        if table is not None:
+            table.close()
+        return None
+    return table
 
 
 class _PythonCollectives:
@@ -275,20 +350,10 @@ class SlabRank:
             if collectives is not None:
                 self.coll = collectives
             elif dist.get_backend() == "nccl":
-                # The library's own communicator; if any rank cannot make one, every rank takes the table over the
-                # process group instead (the ranks agree on that with one reduction, so that they never mix the two).
-                ok = 1
-                try:
-                    self.coll = RcclCollectives(torch, dist, rank, world, dev)
-                except Exception as e:  # noqa: BLE001 - whatever went wrong, the fallback is the same
-                    import sys
-                    print("msm_amd.slab: rank %d: %s; collectives through torch.distributed instead" % (rank, e), file=sys.stderr)
-                    ok = 0
-                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if int(flag.item()) == 0:
-                    if self.coll is not None:
-                        self.coll.close()
+                # The library's own communicator, or - when any rank cannot make one - the table over the process group on
+                # every rank (rccl_table_or_none keeps the ranks on one sequence of collectives while they find out).
+                self.coll = rccl_table_or_none(torch, dist, rank, world, dev)
+                if self.coll is None:
                     self.coll = TorchCollectives(torch, dist, rank, world, dev)
             else:
                 self.coll = HostStagedCollectives(torch, dist, rank, world, dev)

@@ -414,3 +414,22 @@ def test_unmodified_reference_drivers_build_against_include_and_link_the_library
     assert run("nonperiodic", data("changaN8")).stdout.strip() == "u is %15s" % fx["printed"]
     fx = O.golden("ewaldClassical_NaClN8.json")
     assert float(run("ewaldClassical", data("NaClN8"), *fx["args"][1:]).stdout.strip().split()[-1]) == fx["total"]
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """bench.py --gpus N starts N ranks or fails: with fewer devices than ranks (none here) it exits non-zero with a
+    message and prints no result line; a launcher whose WORLD_SIZE disagrees with --gpus is refused too."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("this machine has the devices")
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MSM_AMD_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0
+    assert "needs 2 devices" in r.stderr and "{" not in r.stdout
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0"), capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "must agree" in r.stderr and "{" not in r.stdout

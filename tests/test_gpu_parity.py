@@ -1086,3 +1086,77 @@ def test_prolongation_chain_is_two_prolongations(msm, torch, p):
     for l in range(4):
         assert grid_err(out[0][2][l], sp.grid("e", l)) < TOL, l
     eng.close()
+
+
+def test_ten_million_properties(msm, torch):
+    """N = 10M, quintic spline, the reference's parameter choices: grid 256^3, six levels, 19-tap stencils - the size of
+    the accuracy sweep, where the oracle's whole evaluation is out of reach.  What is asserted at this size: finite and
+    bitwise repeatable; charge conserved on every level; the short-range accelerations of the particles of a sub-box
+    equal the oracle's pair sum over that sub-box and its neighbourhood to 1e-12; and the accelerations of a random
+    subset of 20 000 particles agree with the converged Ewald sum of all 10M to the accuracy of the method at these
+    parameters (6.8e-5 in the sweep table; asserted below 1.5e-4)."""
+    N, A, p = 10000000, (1.0, 1.0, 1.0), 6
+    r, q = O.neutral_system(N, A, seed=20261111 + 5)
+    desc = msm.plan_auto(N, A, p, 10, 4.0, 0)
+    assert list(desc.M) == [256, 256, 256] and desc.L == 6
+    eng = msm.Engine(desc)
+    rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
+    en, acc = eng.eval(rd, qd)
+    assert np.isfinite(en).all() and bool(torch.isfinite(acc).all())
+    for l in range(desc.L):
+        assert abs(eng.grid(msm.capi.GRID_Q, l).sum() - q.sum()) < 1e-7, l
+    en2, acc2 = eng.eval(rd, qd)
+    assert np.array_equal(en, en2) and torch.equal(acc, acc2)
+    del acc2
+    # short-range part on a sub-box: every partner of a particle of the inner cube lies in the outer one, which is far
+    # from the cell's faces, so the oracle's periodic pair sum over the outer cube's particles alone is the same sum
+    a_s = torch.zeros((N, 3), dtype=torch.float64, device="cuda:0")
+    eng.stage_bin(rd, qd)
+    eng.stage_pairs(a_s)
+    lo, w = 0.43, 0.06
+    outer = np.nonzero(((r > lo - desc.a) & (r < lo + w + desc.a)).all(axis=1))[0]
+    inner = ((r[outer] > lo) & (r[outer] < lo + w)).all(axis=1)
+    assert inner.sum() > 1500 and len(outer) < 30000
+    sp = O.SpecPlan.explicit(len(outer), list(desc.A), [8, 8, 8], p, 2, 1, desc.a, 4.0, 2, nthreads=16)  # (only its pair sum is used)
+    aw, _, _ = sp.pairs(r[outer], q[outer])
+    got = a_s[torch.as_tensor(outer, device="cuda:0")].cpu().numpy()
+    assert rel_rms(got[inner], aw[inner]) < TOL
+    assert np.abs(got[inner] - aw[inner]).max() <= 1e-11 * np.abs(aw[inner]).max()
+    del a_s
+    # accuracy against the Ewald sum at a subset (the subset in front, both parts sorted by cell for the Ewald kernels)
+    nsub = 20000
+    first = np.random.default_rng(5).permutation(N)
+    nb = 32
+    cell = np.minimum((r[first] * nb).astype(np.int64), nb - 1)
+    key = (cell[:, 2] * nb + cell[:, 1]) * nb + cell[:, 0] + (np.arange(N) >= nsub) * nb ** 3
+    order = first[np.argsort(key, kind="stable")]
+    sub = order[:nsub]
+    rcut = 0.25
+    alpha = 5.6 / rcut
+    _, _, grad = msm.ewald(rd[torch.as_tensor(order, device="cuda:0")], qd[torch.as_tensor(order, device="cuda:0")], A, alpha, rcut,
+                           int(np.ceil(5.6 * alpha / np.pi)), 0, nsub)
+    ferr = rel_rms(acc[torch.as_tensor(sub, device="cuda:0")].cpu().numpy(), grad.cpu().numpy())
+    assert ferr < 1.5e-4, ferr
+    eng.close()
+
+
+def test_open_boundary_one_million(msm, torch):
+    """The non-periodic MSM (msm3d, msm/msmLibrary.h:216) at 1M particles - the fourth benchmark configuration - against
+    the all-pairs direct sum of the same system on the GPU (direct, msm/msmLibrary.h:212; what msm/nonperiodic.c
+    computes): force error and energy error of the method at a = 4 h, quintic spline, and bitwise repeatable."""
+    N, p, mu = 1000000, 6, 10
+    r, q = open_system(N, 13)
+    ht = (1.0 / N) ** (1.0 / 3.0)
+    desc = msm.plan_open(N, r.min(axis=0), r.max(axis=0), p, mu, ht, 4.0 * ht, 0)
+    assert desc.open_boundary == 1 and max(desc.M) >= 128
+    eng = msm.Engine(desc)
+    rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
+    en, acc = eng.eval(rd, qd)
+    en2, acc2 = eng.eval(rd, qd)
+    assert np.isfinite(en).all() and np.array_equal(en, en2) and torch.equal(acc, acc2)
+    for l in range(desc.L):
+        assert abs(eng.grid(msm.capi.GRID_Q, l).sum() - q.sum()) < 1e-8, l
+    u, f = msm.direct(r, q)
+    assert abs(en[6] - u) < 1e-2 * abs(u)
+    assert rel_rms(acc.cpu().numpy(), f) < 3e-4
+    eng.close()

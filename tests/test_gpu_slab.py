@@ -383,7 +383,9 @@ def _one_rank_steps(rank, world, options, steps=3, kind="halo"):
     for _ in range(steps):
         s.step(want_energies=False)
     torch.cuda.synchronize()
-    return s.acc[:s.n_own].clone(), s.sums.clone()
+    out = s.acc[:s.n_own].clone(), s.sums.clone()
+    s.eng.close()      # (and with it the handle's two streams: the cases of a test do not pile them up)
+    return out
 
 
 @pytest.mark.parametrize("rank", [0, 2])
@@ -466,3 +468,58 @@ def test_slab_convolution_of_19_taps_in_tall_tiles():
         assert float(((sums - ref_sums).abs() / ref_sums.abs().clamp_min(1e-300)).max()) <= 1e-11, planes
         if planes == 0:
             assert torch.equal(acc, ref_acc)      # a grid of 96 x 96 nodes has too few tiles for the tall ones
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """python bench.py --gpus 2 with no launcher around it: the parent starts two ranks (here sharing the one GPU, with the
+    collectives staged through the host: a rehearsal of the launch path, labelled as such, not a measurement) and
+    forwards rank 0's line, which says two ranks ran, what each of them held, and carries the per-rank roofline."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MSM_AMD_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--particles", "40000", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-accuracy"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
+    mg = out["multi_gpu"]
+    assert len(mg["per_rank"]) == 2 and sum(x["n_owned"] for x in mg["per_rank"]) == 40000
+    assert all(x["n_total"] > x["n_owned"] for x in mg["per_rank"])
+    assert "rehearsal" in out["config"] and out["roofline"]["frac"] > 0
+    assert np.isfinite(list(out["energies_last_timed_step"].values())).all()
+
+
+def test_rank_of_eight_at_ten_million_tall_tiles():
+    """One rank of 8 of the 10M-particle system (grid 256^3, 32 owned planes, 19-tap stencils, halo exchange) with
+    collectives that move nothing: the level-0 convolution of its 38 planes by the whole-grid kernel in one layer of tall
+    tiles (what the step chooses at this size) and by the slab kernel in tiles of 8 planes add the taps in different
+    orders - equal to rounding - and each is bitwise repeatable."""
+    import torch
+    import msm_amd
+    from msm_amd.slab import SlabRank, NullCollectives
+    N, world, rank = 10000000, 8, 3
+    r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=20261111 + 5)
+    desc = msm_amd.plan_auto(N, (1.0, 1.0, 1.0), 6, 10, 4.0, 0)
+    assert list(desc.M) == [256, 256, 256]
+    res = {}
+    for planes in (0, 8, 0):
+        s = SlabRank(torch, _NoDist(), msm_amd, desc, r, q, rank, world, 0, perturb=False, collectives=NullCollectives(rank, world))
+        assert s.eng.slab_exchange_mode(world, 0) == 2
+        s.eng.set_option("conv_tile_planes", planes)
+        for _ in range(2):
+            s.step(want_energies=False)
+        torch.cuda.synchronize()
+        acc, sums = s.acc[:s.n_own].clone(), s.sums.clone()
+        s.eng.close()
+        assert bool(torch.isfinite(acc).all()) and 1.2e6 < s.n_own < 1.3e6
+        if planes in res:
+            assert torch.equal(acc, res[planes][0]) and torch.equal(sums, res[planes][1])
+        res[planes] = (acc, sums)
+    scale = float(res[0][0].abs().max())
+    assert float((res[0][0] - res[8][0]).abs().max()) <= 1e-12 * scale
+    assert float(((res[0][1] - res[8][1]).abs() / res[0][1].abs().clamp_min(1e-300)).max()) <= 1e-11

@@ -255,3 +255,77 @@ def test_open_slab_partition_is_exact_and_balanced():
             assert np.array_equal(np.sort(hal), want)
         assert (seen == 1).all()
         assert max(counts) < 1.35 * (N / world), counts        # cuts fall on planes, so not perfectly even
+
+
+class _FakeRcclApi:
+    """Stand-in for the three library calls of rccl_table_or_none that fails where the test says."""
+
+    class Table:
+        closed = False
+
+        def close(self):
+            self.closed = True
+
+    def __init__(self, rank, fail):
+        self.rank, self.fail, self.calls, self.table = rank, fail, [], None
+
+    def _maybe(self, what):
+        self.calls.append(what)
+        if self.fail == (what, self.rank):
+            raise RuntimeError("injected failure of %s on rank %d" % (what, self.rank))
+
+    def available(self):
+        self._maybe("available")
+
+    def unique_id(self):
+        self._maybe("unique_id")
+        return bytes(range(128))
+
+    def create(self, raw, rank, world):
+        assert raw == bytes(range(128))
+        self._maybe("create")
+        self.table = self.Table()
+        return self.table
+
+
+def _agree_worker(rank, world, port, cases, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(60, exit=True)
+    import json
+    import torch
+    import torch.distributed as dist
+    from msm_amd.slab import rccl_table_or_none
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = []
+    for fail in cases:
+        api = _FakeRcclApi(rank, tuple(fail) if fail else None)
+        t = rccl_table_or_none(torch, dist, rank, world, "cpu", api=api)
+        res.append({"got": t is not None, "calls": api.calls, "closed": bool(api.table is not None and api.table.closed)})
+        dist.barrier()       # every rank left the negotiation: nobody is stuck in a collective the others skipped
+    with open(os.path.join(out_dir, "agree%d.json" % rank), "w") as f:
+        json.dump(res, f)
+    dist.destroy_process_group()
+
+
+def test_rccl_negotiation_keeps_the_ranks_together(tmp_path):
+    """msm_amd.slab.rccl_table_or_none with a failure injected on rank 0 or on rank 1 at each of its three library calls:
+    both ranks come out with the same answer (no table), having run the same collectives, and a communicator that was
+    made on one rank only is destroyed again."""
+    import json
+    import torch.multiprocessing as mp
+    cases = [None, ("available", 0), ("available", 1), ("unique_id", 0), ("create", 0), ("create", 1)]
+    world = 2
+    mp.spawn(_agree_worker, args=(world, _free_port(), cases, str(tmp_path)), nprocs=world, join=True)
+    res = [json.load(open(os.path.join(str(tmp_path), "agree%d.json" % k))) for k in range(world)]
+    for i, fail in enumerate(cases):
+        got = [res[k][i]["got"] for k in range(world)]
+        assert got == [fail is None] * world, (fail, got)
+        if fail and fail[0] == "available":     # nobody went on to the library's collective calls
+            assert all("create" not in res[k][i]["calls"] and "unique_id" not in res[k][i]["calls"] for k in range(world))
+        if fail and fail[0] == "unique_id":
+            assert all("create" not in res[k][i]["calls"] for k in range(world))
+        if fail and fail[0] == "create":        # the rank whose communicator came up gave it back
+            other = 1 - fail[1]
+            assert res[other][i]["closed"] and not res[fail[1]][i]["closed"]
