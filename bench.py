@@ -25,8 +25,8 @@ functional rehearsal with ranks sharing devices and is labelled as such in the l
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_pair_clusters_filtered, the short-range pair
 sum): algorithmic flops (ordered in-cutoff pairs x 34 flop at p=4 / 42 at p=6) over that kernel's mean
 duration, measured with a pair of HIP events recorded around it on the stream it runs on.  `traffic` is the
-HBM-side byte count of one launch from rocprofv3 PMC passes (profiles/r01_pair_traffic.json; null if that
-file is absent).  `cpu_baseline` is the CPU oracle (a port of the same mathematics, oracle/msm_spec.c) timed on
+HBM-side byte count of one launch from rocprofv3 PMC passes (the newest profiles/r*_pair_traffic.json; null if none
+is there).  `cpu_baseline` is the CPU oracle (a port of the same mathematics, oracle/msm_spec.c) timed on
 this box's host cores on one evaluation of the same system (`reference_literal` inside it: the reference's own
 algorithm on one core at the sizes it can run); `parity` compares the GPU result with it.
 """
@@ -78,6 +78,11 @@ def main():
     ap.add_argument("--pair-variant", type=int, default=-1)
     ap.add_argument("--no-accuracy", action="store_true", help="skip the Ewald reference (error of the MSM result)")
     ap.add_argument("--opts", default="", help="engine options for A/B runs, key=value,key=value (msm_amd_set_option)")
+    ap.add_argument("--reference-binary", action="store_true",
+                    help="cpu_baseline: also run the real msmPeriodic (oracle/_ref, when it was built) at N = 8 and 64 (about 10 s)")
+    ap.add_argument("--literal-n", type=int, default=0,
+                    help="cpu_baseline: also time the literal mirror on a synthetic system of this many particles "
+                         "(4096 takes about three minutes on one core)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be at least 1")
@@ -190,7 +195,7 @@ def main():
 
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, cpu_out = cpu_baseline(desc, r_all, q_all)
+        cpu, cpu_out = cpu_baseline(desc, r_all, q_all, args.reference_binary, args.literal_n)
         en_gpu, acc_gpu = ref_eval
         en_cpu = cpu_out["energies"]
         scale = float(np.abs(en_cpu[:6]).max())
@@ -209,9 +214,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_accuracy:
         accuracy = ewald_accuracy(torch, msm_amd, r_all, q_all, A, ref_eval[0], ref_eval[1], dev)
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02_pair_traffic.json")
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "r01_pair_traffic.json")
+    tpath = next((t for t in (os.path.join(ROOT, "profiles", "r%02d_pair_traffic.json" % k) for k in (3, 2, 1)) if os.path.exists(t)),
+                 "")
     if world == 1 and N == 1000000 and os.path.exists(tpath):  # the counters were taken on the default workload
         with open(tpath) as f:
             traffic = json.load(f).get("order%d" % p, {}).get("hbm_bytes_per_launch")
@@ -241,6 +245,10 @@ def main():
                          "bound": "valu_fp64", "achieved": achieved,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                          "traffic": traffic, "kernel_ms": pair_s * 1e3,
+                         "sustained_peak": 64.0, "frac_of_sustained": achieved / 64.0,
+                         "sustained_peak_source": "measured issue rate of v_fma_f64 (tools/micro/valu_rate.hip: one per 2.04 ns per "
+                                                  "SIMD with four waves resident = 64 TFLOP/s for the chip); `frac` stays "
+                                                  "against the data-sheet peak",
                          "note": "FP64 vector FMA bound (the FP64 MFMA peak is the same 78.6 TF); algorithmic flops = "
                                  "N*(4pi/3)*abar^3 ordered pairs x %d flop" % FLOP_PER_PAIR[p]},
             "kernel_ms": acc_ms,
@@ -437,10 +445,11 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(desc, r, q):
+def cpu_baseline(desc, r, q, reference_binary=False, literal_n=0):
     """The CPU oracle (oracle/msm_spec.c: the same mathematics as the GPU path, C + OpenMP) on this box's cores, and
-    the reference's own algorithm on one core in the only regime it can run (N <= 512)."""
+    the reference's own algorithm on one core in the only regime it can run (N <= a few thousand)."""
     import oracle_lib as O
+    import msm_amd
     # the cores this job may use: the box exports its share as OMP_NUM_THREADS (os.cpu_count() is the whole machine)
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
     sp = O.SpecPlan.explicit(desc.N, list(desc.A), list(desc.M), desc.p, desc.mu, desc.L, desc.a, desc.beta, desc.kmax,
@@ -449,25 +458,41 @@ def cpu_baseline(desc, r, q):
     out = sp.eval(r, q)
     dt = time.perf_counter() - t0
     names = ("pairs", "anterpolation", "restriction", "convolution", "top", "prolongation", "interpolation", "total")
+    # the same port at the size of the second benchmark configuration (100k particles, cubic spline, three levels), on
+    # one core - the reference is single-threaded - and on all of them
+    small = {}
+    N2 = 100000
+    r2, q2 = make_system(N2, 20261111 + 1)
+    d2 = msm_amd.plan_auto(N2, (1.0, 1.0, 1.0), 4, 10, 4.0, 3)
+    for nt in (1, cores):
+        sp2 = O.SpecPlan.explicit(d2.N, list(d2.A), list(d2.M), d2.p, d2.mu, d2.L, d2.a, d2.beta, d2.kmax, nthreads=nt)
+        t1 = time.perf_counter()
+        o2 = sp2.eval(r2, q2)
+        d = time.perf_counter() - t1
+        small["cores_%d" % nt] = {"cores": nt, "seconds": d, "evals_per_s": 1.0 / d,
+                                  "stage_seconds": dict(zip(names, [float(x) for x in o2["seconds"]]))}
+        sp2.close()
     return {"value": 1.0 / dt, "unit": "evals/s", "cores": cores, "kind": "port",
             "host": {"cpu_model": cpu_model(), "cpus_of_the_machine": os.cpu_count(), "cpus_used": cores},
             "sample": "1 evaluation of the same %d-particle system (all stages)" % desc.N,
             "note": "an unoptimised port: its anterpolation alone takes more than half of the time",
             "stage_seconds": dict(zip(names, [float(x) for x in out["seconds"]])),
             "utotal": float(out["energies"][6]),
-            "reference_literal": reference_literal_timings()}, out
+            "port_100k_order4_3levels": small,
+            "reference_literal": reference_literal_timings(reference_binary, literal_n)}, out
 
 
-def reference_literal_timings():
+def reference_literal_timings(reference_binary=False, literal_n=0):
     """The reference's algorithm itself, single-threaded as the reference is (msmPeriodic.c:52, "time total" of
-    msmLibrary.c:337), on the systems of msm/data it can execute: the literal mirror oracle/msm_literal.c (stage for stage
-    the reference's arithmetic; its image sums are tabulated, so its stencil set-up is faster than the reference's) at
-    N = 8, 64, 512, and - when the reference itself was built into oracle/_ref - the real msmPeriodic at N = 8 and 64
-    with its own clock() split between stencil set-up and everything else."""
+    msmLibrary.c:337), on the systems it can execute: the literal mirror oracle/msm_literal.c (stage for stage the
+    reference's arithmetic; its image sums are tabulated, so its stencil set-up is faster than the reference's) at
+    N = 8, 64, 512 of msm/data and, with --literal-n, on a synthetic system of that size (4096: the largest the
+    algorithm is meaningful for; minutes); with --reference-binary and the reference built into oracle/_ref, the real
+    msmPeriodic at N = 8 and 64 with its own clock() split between stencil set-up and everything else."""
     import subprocess
     import tempfile
     import oracle_lib as O
-    res = {"cores": 1, "mirror": {}, "reference_binary": {}}
+    res = {"cores": 1, "mirror": {}, "reference_binary": "not requested (--reference-binary)"}
     for name in ("changaN8", "changaN64", "changaN512"):
         fx = O.golden("msmPeriodic_%s.json" % name)
         sysd = fx["system"]
@@ -477,8 +502,17 @@ def reference_literal_timings():
         dt = time.perf_counter() - t0
         res["mirror"][name] = {"N": sysd["N"], "seconds": dt, "evals_per_s": 1.0 / dt, "utotal": float(lit["u_total"]),
                                "reference_recorded_seconds": float(fx["stats"]["time total"])}
+    if literal_n > 0:
+        rr, qq = make_system(literal_n, 20261111 + 0)
+        t0 = time.perf_counter()
+        lit = O.literal_run(rr, qq, 4, 4.0, 10, (1.0, 1.0, 1.0))
+        dt = time.perf_counter() - t0
+        res["mirror"]["synthetic_N%d" % literal_n] = {"N": literal_n, "seconds": dt, "evals_per_s": 1.0 / dt,
+                                                      "utotal": float(lit["u_total"]),
+                                                      "system": "SplitMix64 seed 20261111, unit cube, charges +1 / -1"}
     exe = os.path.join(ROOT, "oracle", "_ref", "msmPeriodic")
-    if os.path.exists(exe):
+    if reference_binary and os.path.exists(exe):
+        res["reference_binary"] = {}
         for name in ("changaN8", "changaN64"):
             fx = O.golden("msmPeriodic_%s.json" % name)
             sysd = fx["system"]
@@ -505,7 +539,7 @@ def reference_literal_timings():
                                              "without_stencil_setup": total - sten,
                                              "evals_per_s_with_setup": 1.0 / total,
                                              "evals_per_s_without_setup": 1.0 / max(total - sten, 1e-9)}
-    else:
+    elif reference_binary:
         res["reference_binary"] = "oracle/_ref/msmPeriodic is not built on this machine"
     return res
 
