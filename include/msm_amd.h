@@ -197,7 +197,8 @@ int msm_amd_get_mode(void);
  * call that takes the scalable path says so on stderr unless msm_amd_set_quiet(1). */
 int msm_amd_last_call_mode(void);
 /* msmperiodic(), msmPeriodicRunner() and msm3d() keep the plan of their last call (stencils and device buffers) and
- * reuse it when the next call needs the same one; this frees it. */
+ * reuse it when the next call needs the same one, and direct() keeps its device copies of the caller's arrays; this
+ * frees both. */
 void msm_amd_release_cached_plan(void);
 /* number of plans those three entry points have built in this process (a call that reuses the kept plan adds nothing) */
 long msm_amd_plan_builds(void);

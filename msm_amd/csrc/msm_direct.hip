@@ -198,6 +198,34 @@ extern "C" int msm_amd_direct_device_noalloc(int N, const double *d_r, const dou
     return MSM_AMD_OK;
 }
 
+namespace {
+struct DirectStaging {
+    int device = -1;
+    size_t n = 0, nw = 0;
+    double *r = nullptr, *q = nullptr, *acc = nullptr, *work = nullptr;
+} g_stage;
+std::mutex g_stage_mu;
+void direct_release_staging_locked() {
+    if (g_stage.device >= 0) {
+        int cur = 0;
+        const bool have = hipGetDevice(&cur) == hipSuccess;
+        if (have && cur != g_stage.device) (void)hipSetDevice(g_stage.device);
+        (void)hipFree(g_stage.r); (void)hipFree(g_stage.q); (void)hipFree(g_stage.acc); (void)hipFree(g_stage.work);
+        if (have && cur != g_stage.device) (void)hipSetDevice(cur);
+    } else {
+        (void)hipFree(g_stage.r); (void)hipFree(g_stage.q); (void)hipFree(g_stage.acc); (void)hipFree(g_stage.work);
+    }
+    g_stage = DirectStaging();
+}
+} // namespace
+// (called by msm_amd_release_cached_plan)
+namespace msm {
+void direct_release_staging() {
+    std::lock_guard<std::mutex> lock(g_stage_mu);
+    direct_release_staging_locked();
+}
+} // namespace msm
+
 // replaces direct(), declared at msm/msmLibrary.h:212 and defined nowhere in the reference; computation of
 // msm/nonperiodic.c:12-22 plus the gradient.  Host pointers in and out; failures print to stderr (the reference's
 // convention, no return code) and leave *ureal = 0.
@@ -210,12 +238,22 @@ extern "C" void direct(int N, double *r, double *q, double *ureal, double *freal
         return;
     }
     if (N < 1 || !r || !q) return;
-    double *d_r = nullptr, *d_q = nullptr, *d_acc = nullptr, *d_work = nullptr;
+    // device copies of the caller's arrays: kept from call to call (a driver calls direct() in a loop), grown when a
+    // larger system arrives, released by msm_amd_release_cached_plan()
+    std::lock_guard<std::mutex> lock(g_stage_mu);
+    int dev = 0;
+    bool ok = hipGetDevice(&dev) == hipSuccess;
     const size_t nw = (size_t)msm_amd_direct_work_doubles(N);
-    bool ok = hipMalloc((void **)&d_r, sizeof(double) * 3 * (size_t)N) == hipSuccess &&
-              hipMalloc((void **)&d_q, sizeof(double) * (size_t)N) == hipSuccess &&
-              hipMalloc((void **)&d_acc, sizeof(double) * 3 * (size_t)N) == hipSuccess &&
-              hipMalloc((void **)&d_work, sizeof(double) * nw) == hipSuccess;
+    if (ok && (g_stage.device != dev || g_stage.n < (size_t)N || g_stage.nw < nw)) {
+        direct_release_staging_locked();
+        ok = hipMalloc((void **)&g_stage.r, sizeof(double) * 3 * (size_t)N) == hipSuccess &&
+             hipMalloc((void **)&g_stage.q, sizeof(double) * (size_t)N) == hipSuccess &&
+             hipMalloc((void **)&g_stage.acc, sizeof(double) * 3 * (size_t)N) == hipSuccess &&
+             hipMalloc((void **)&g_stage.work, sizeof(double) * nw) == hipSuccess;
+        if (ok) { g_stage.device = dev; g_stage.n = (size_t)N; g_stage.nw = nw; }
+        else direct_release_staging_locked();
+    }
+    double *d_r = g_stage.r, *d_q = g_stage.q, *d_acc = g_stage.acc, *d_work = g_stage.work;
     ok = ok && hipMemcpy(d_r, r, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(d_q, q, sizeof(double) * (size_t)N, hipMemcpyHostToDevice) == hipSuccess;
     double u = 0.0;
@@ -227,5 +265,4 @@ extern "C" void direct(int N, double *r, double *q, double *ureal, double *freal
     } else if (ureal) {
         *ureal = u;
     }
-    hipFree(d_r); hipFree(d_q); hipFree(d_acc); hipFree(d_work);
 }

@@ -55,6 +55,7 @@ struct msm_amd_handle {
     double *dTsum = nullptr, *dTfour = nullptr; // coarsest-level + Fourier stencils as offset tables (both span one period)
     int opt_top_fused = 1;
     LevelStencil lit_part[2]; // literal mode: gamma / erf terms of the level-0 stencil (diagnostic energies), built on first use
+    double *lit_part_d[2] = {nullptr, nullptr}, *lit_part_e = nullptr; // their device copies and the potential they give (first use)
     double *open_part = nullptr; // open boundaries: partial sums of the coarsest level's all-pairs convolution
     int opt_sort_two_level = 1; // creation-time choice (MSM_AMD_SORT=0 in the environment selects the sort with global counters)
     // reductions
@@ -508,6 +509,7 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     hipFree(h->d_energies);
     if (h->h_energies) hipHostFree(h->h_energies);
     hipFree(h->s_r); hipFree(h->s_q); hipFree(h->s_acc); hipFree(h->s_acc2); hipFree(h->conv_part);
+    hipFree(h->lit_part_d[0]); hipFree(h->lit_part_d[1]); hipFree(h->lit_part_e);
     if (h->stream_b) {
         hipStreamSynchronize(h->stream_b);
         hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_pairs); hipEventDestroy(h->ev_join);
@@ -1740,9 +1742,13 @@ extern "C" long msm_amd_plan_builds(void) {
     std::lock_guard<std::mutex> lock(g_plan_cache.mu);
     return g_plan_builds;
 }
+namespace msm { void direct_release_staging(); }
 extern "C" void msm_amd_release_cached_plan(void) {
-    std::lock_guard<std::mutex> lock(g_plan_cache.mu);
-    drop_cached_plan();
+    {
+        std::lock_guard<std::mutex> lock(g_plan_cache.mu);
+        drop_cached_plan();
+    }
+    msm::direct_release_staging(); // the device copies direct() keeps between calls
 }
 
 extern "C" msm_stats msmperiodic(int N, double *r, double *q, int p, double abar, int mu, double *uappr, double *fappr,
@@ -1929,15 +1935,16 @@ extern "C" msm_stats msmperiodic(int N, double *r, double *q, int p, double abar
         for (int k = 0; k < 2 && pok; k++) {
             const LevelStencil &P = h->lit_part[k];
             std::vector<double> e(n0);
-            double *dKp = nullptr, *dEp = nullptr;
-            pok = dalloc(&dKp, P.v.size()) == MSM_AMD_OK && dalloc(&dEp, n0) == MSM_AMD_OK &&
-                  hip_ok(hipMemcpy(dKp, P.v.data(), P.v.size() * sizeof(double), hipMemcpyHostToDevice), "copy of a part stencil");
+            // (device copies made once per plan and kept in the handle: a driver loop allocates nothing here)
+            if (!h->lit_part_d[k])
+                pok = dalloc(&h->lit_part_d[k], P.v.size()) == MSM_AMD_OK &&
+                      hip_ok(hipMemcpy(h->lit_part_d[k], P.v.data(), P.v.size() * sizeof(double), hipMemcpyHostToDevice), "copy of a part stencil");
+            if (pok && !h->lit_part_e) pok = dalloc(&h->lit_part_e, n0) == MSM_AMD_OK;
             if (pok) {
-                launch_conv_literal(h->stream, h->gq[0], dKp, h->hp.Ml[0], P.size, P.first, dEp);
+                launch_conv_literal(h->stream, h->gq[0], h->lit_part_d[k], h->hp.Ml[0], P.size, P.first, h->lit_part_e);
                 pok = hip_ok(hipStreamSynchronize(h->stream), "part convolution") &&
-                      hip_ok(hipMemcpy(e.data(), dEp, n0 * sizeof(double), hipMemcpyDeviceToHost), "copy of a part potential");
+                      hip_ok(hipMemcpy(e.data(), h->lit_part_e, n0 * sizeof(double), hipMemcpyDeviceToHost), "copy of a part potential");
             }
-            hipFree(dKp); hipFree(dEp);
             if (pok) for (size_t i = 0; i < n0; i++) part_u[k] += 0.5 * e[i] * g0[i];
         }
         if (pok) {
