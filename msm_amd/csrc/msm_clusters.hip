@@ -703,7 +703,8 @@ __device__ __forceinline__ LaneI load_lane_i(const ClusterGeom &g, const Cluster
 
 // sum the 8 lanes that share a particle i (consecutive lanes), then write its acceleration and energy share
 __device__ __forceinline__ void cl_finish(const LaneI &I, const PairParams &pp, int jj, int icl, double u, double fx, double fy,
-                                          double fz, double *__restrict__ acc, double *__restrict__ epart, int lane) {
+                                          double fz, double *__restrict__ acc, double *__restrict__ epart, int lane,
+                                          double4 *__restrict__ acc_slots = nullptr) {
 #pragma unroll
     for (int off = 1; off < CL_G; off <<= 1) {
         u += __shfl_xor(u, off);
@@ -714,9 +715,13 @@ __device__ __forceinline__ void cl_finish(const LaneI &I, const PairParams &pp, 
     double e = 0.0;
     if (jj == 0 && I.owned) {
         const double w = pp.convention == MSM_AMD_ACC_FORCE ? -I.q : 1.0;
-        acc[3 * (size_t)I.orig] = w * fx;
-        acc[3 * (size_t)I.orig + 1] = w * fy;
-        acc[3 * (size_t)I.orig + 2] = w * fz;
+        if (acc_slots) { // by slot: lane (ii, 0) holds particle ii of the cluster
+            acc_slots[(size_t)CL_G * icl + (lane >> 3)] = make_double4(w * fx, w * fy, w * fz, 0.0);
+        } else {
+            acc[3 * (size_t)I.orig] = w * fx;
+            acc[3 * (size_t)I.orig + 1] = w * fy;
+            acc[3 * (size_t)I.orig + 2] = w * fz;
+        }
         e = 0.5 * I.q * u;
     }
     e = wave_sum(e);
@@ -794,7 +799,7 @@ __global__ __launch_bounds__(256) void k_pair_clusters(ClusterGeom g, ClusterBuf
         shift_of_code(g, (int)((unsigned)ent >> CL_CODE_SHIFT), sx, sy, sz);
         cl_slot<P, false>(I.x - sx, I.y - sy, I.z - sz, pj[(size_t)CL_G * (ent & CL_JMASK)], pp, true, uh, fx, fy, fz);
     }
-    cl_finish(I, pp, jj, icl, 2.0 * u1 + uh, fx, fy, fz, acc, epart, lane);
+    cl_finish(I, pp, jj, icl, 2.0 * u1 + uh, fx, fy, fz, acc, epart, lane, b.acc_slots);
 }
 
 // The list walked at particle granularity.  A listed cluster j has, on average, only a third of its particles
@@ -968,7 +973,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_pair_clusters_filtered(Cluste
     else walk(L + MID, 1, nd, false, No{}, uh);
     if (!HALF) walk(L + MID - 1, -1, min(max(b.n3[icl], 0), MID - 1), false, No{}, uh); // (never beyond its half of the list)
     walk(L + S - 1, -1, ns, true, No{}, uh);
-    cl_finish(I, pp, jj, icl, 2.0 * u1 + uh, fx, fy, fz, acc, epart, lane);
+    cl_finish(I, pp, jj, icl, 2.0 * u1 + uh, fx, fy, fz, acc, epart, lane, b.acc_slots);
     trace(3);
     }();
 }
@@ -1143,7 +1148,7 @@ __global__ __launch_bounds__(256, 4) void k_pair_clusters_split(ClusterGeom g, C
 
     // sum the CLS_W lanes that share a particle i, write its acceleration and energy share
     double e = 0.0;
-    auto finish = [&](const LaneI &I, double u, double fx, double fy, double fz) {
+    auto finish = [&](const LaneI &I, int member, double u, double fx, double fy, double fz) {
 #pragma unroll
         for (int off = 1; off < CLS_W; off <<= 1) {
             u += __shfl_xor(u, off);
@@ -1153,14 +1158,18 @@ __global__ __launch_bounds__(256, 4) void k_pair_clusters_split(ClusterGeom g, C
         }
         if (jj == 0 && I.owned) {
             const double w = pp.convention == MSM_AMD_ACC_FORCE ? -I.q : 1.0;
-            acc[3 * (size_t)I.orig] = w * fx;
-            acc[3 * (size_t)I.orig + 1] = w * fy;
-            acc[3 * (size_t)I.orig + 2] = w * fz;
+            if (b.acc_slots) {
+                b.acc_slots[(size_t)CL_G * icl + member] = make_double4(w * fx, w * fy, w * fz, 0.0);
+            } else {
+                acc[3 * (size_t)I.orig] = w * fx;
+                acc[3 * (size_t)I.orig + 1] = w * fy;
+                acc[3 * (size_t)I.orig + 2] = w * fz;
+            }
             e += 0.5 * I.q * u;
         }
     };
-    finish(IA, 2.0 * u1A + uhA, fxA, fyA, fzA);
-    finish(IB, 2.0 * u1B + uhB, fxB, fyB, fzB);
+    finish(IA, hh, 2.0 * u1A + uhA, fxA, fyA, fzA);
+    finish(IB, CL_G / 2 + hh, 2.0 * u1B + uhB, fxB, fyB, fzB);
     e = wave_sum(e);
     if (lane == 0) epart[icl] = e;
 }
@@ -1205,7 +1214,7 @@ __device__ __forceinline__ void direct_one_cluster(const ClusterGeom &g, const C
             }
         }
     });
-    cl_finish(I, pp, jj, icl, 2.0 * u1 + uh, fx, fy, fz, acc, epart, lane);
+    cl_finish(I, pp, jj, icl, 2.0 * u1 + uh, fx, fy, fz, acc, epart, lane, b.acc_slots);
 }
 
 // every cluster list-free (A/B variant)

@@ -79,6 +79,12 @@ struct msm_amd_handle {
     ClusterGeom clg;
     ClusterBuffers clb = {};
     bool cells_binned = false, clusters_sorted = false, grid_binned = false;
+    // Whole evaluations (msm_amd_eval, msm_amd_slab_step) keep the short-range accelerations in slot order between the
+    // pair kernels and the interpolation kernel, which adds the grid part and writes the caller's array once
+    // (ClusterBuffers::acc_slots); the stage entry points, whose d_acc is the caller's to read after every stage, do not.
+    double4 *acc_slots = nullptr;
+    int opt_acc_slots = 1;      // 0: the pair kernels scatter into the caller's array themselves (A/B)
+    bool fused_acc = false;     // set for the duration of a whole evaluation that qualifies
     // LDS-tiled anterpolation
     TileGeom tiles = {};
     double *tile_scratch = nullptr;
@@ -390,6 +396,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         DA(cb.blo, cg.max_clusters); DA(cb.bhi, cg.max_clusters); DA(cb.fbox, 2 * (size_t)cg.max_clusters);
         DA(cb.list, (size_t)cg.max_clusters * cg.list_stride); DA(cb.n0, cg.max_clusters); DA(cb.n1, cg.max_clusters); DA(cb.n2, cg.max_clusters); DA(cb.n3, cg.max_clusters);
         HIPCHK_H(hipMemset(cb.n3, 0, sizeof(int) * (size_t)cg.max_clusters)); // (a list build without halo copies does not write it)
+        if (cg.kx > 0) DA(h->acc_slots, nslots); // (only grid-aligned columns let the interpolation walk the same slots)
     }
     h->gq.assign(L, nullptr); h->ge.assign(L, nullptr); h->dK.assign(L, nullptr); h->dKt.assign(L, nullptr);
     h->dKsub.assign(L, nullptr); h->sub_s.assign(L, 0); h->sub_n.assign(L, 0);
@@ -510,6 +517,7 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     if (h->h_energies) hipHostFree(h->h_energies);
     hipFree(h->s_r); hipFree(h->s_q); hipFree(h->s_acc); hipFree(h->s_acc2); hipFree(h->conv_part);
     hipFree(h->lit_part_d[0]); hipFree(h->lit_part_d[1]); hipFree(h->lit_part_e);
+    hipFree(h->acc_slots);
     if (h->stream_b) {
         hipStreamSynchronize(h->stream_b);
         hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_pairs); hipEventDestroy(h->ev_join);
@@ -568,6 +576,7 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "anterp_cols_waves")) { if (value == 0 || value == 4 || value == 8 || value == 16) { h->sopt.anterp_cols_waves = value; return MSM_AMD_OK; } }
     if (!strcmp(key, "anterp_cols_order4")) { h->sopt.anterp_cols_order4 = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "anterp_cols")) { h->sopt.anterp_cols = value != 0; return MSM_AMD_OK; }
+    if (!strcmp(key, "acc_slots")) { h->opt_acc_slots = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "overlap")) { h->opt_overlap = value; return MSM_AMD_OK; }
     if (!strcmp(key, "slab_own_stream")) { h->opt_slab_own_stream = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "slab_overlap")) { h->opt_slab_overlap = value; return MSM_AMD_OK; }
@@ -609,6 +618,7 @@ static TileSrc tile_source(msm_amd_handle *h) {
     if (tiles_from_clusters(h)) {
         S.ps = h->clb.ps; S.order = h->clb.order; S.start = h->clb.start; S.clstart = h->clb.clstart;
         S.cg = h->clg; S.cluster_order = 1;
+        S.acc_slots = h->fused_acc ? h->acc_slots : nullptr;
         for (int k = 0; k < 3; k++) S.scale[k] = h->hp.d.M[k] / h->hp.d.A[k];
     } else {
         ensure_grid_binned(h);
@@ -654,7 +664,9 @@ extern "C" int msm_amd_stage_pairs(msm_amd_handle *h, double *d_acc) {
         if (!h->clusters_sorted)
             launch_cluster_sort(h->stream, h->cur_r, h->cur_q, h->N, h->clg, h->clb, h->bin_of, h->arrival, h->slot_idx, h->scan_tmp);
         h->clusters_sorted = true;
-        launch_pair_clusters(h->stream, h->clg, h->clb, h->pp, d_acc, h->epart, h->opt_pair_variant - 5, h->N,
+        ClusterBuffers cb = h->clb;
+        cb.acc_slots = h->fused_acc ? h->acc_slots : nullptr;
+        launch_pair_clusters(h->stream, h->clg, cb, h->pp, d_acc, h->epart, h->opt_pair_variant - 5, h->N,
                              h->profiling ? h->ev_pk : nullptr, h->pair_wgs_now, h->pairs_after, h->opt_pair_lds_pad | (h->opt_pair_wpb << 20) | (h->opt_list_wpb << 24));
         h->pairs_after = nullptr;
         h->pk_recorded = h->profiling && h->opt_pair_variant != 6;
@@ -1142,11 +1154,25 @@ static int ensure_stream_b(msm_amd_handle *h) {
     return MSM_AMD_OK;
 }
 
+// A whole evaluation whose pair sum and interpolation both walk the cluster order passes the short-range accelerations
+// from the one to the other in slot order (see msm_amd_handle::acc_slots).
+namespace {
+struct FusedAcc {
+    msm_amd_handle *h;
+    explicit FusedAcc(msm_amd_handle *hh) : h(hh) {
+        h->fused_acc = h->opt_acc_slots && h->acc_slots && !h->small_box && !h->hp.literal && h->anterp_tiled && h->opt_anterp_tiled &&
+                       h->clg.kx > 0 && h->opt_pair_variant >= 5 && h->pp.convention != MSM_AMD_ACC_LITERAL;
+    }
+    ~FusedAcc() { h->fused_acc = false; }
+};
+} // namespace
+
 extern "C" int msm_amd_eval(msm_amd_handle *h, const double *d_r, const double *d_q, double *d_acc, double *energies) {
     if (!h || !d_r || !d_q || !d_acc) { set_error("msm_amd_eval: null argument"); return MSM_AMD_EINVAL; }
     HIPCHK(hipSetDevice(h->device));
     int rc;
     h->pk_recorded = false;
+    FusedAcc fused(h);
     const bool overlap = can_overlap(h);
     if (overlap && (rc = ensure_stream_b(h))) return rc;
     mark(h, T_BIN);
@@ -1327,6 +1353,7 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
     }
     HIPCHK(hipSetDevice(h->device));
     int rc;
+    FusedAcc fused(h);
     // Two streams: the exchange of the grid charges (and, in halo mode, the first restriction and the all-gather of
     // the level-1 charges) travels on the second one while the first builds the lists and computes the pair sum, which
     // need nothing from the other ranks.  What else follows the exchange on the second stream is opt_slab_overlap's:

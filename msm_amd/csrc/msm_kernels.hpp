@@ -110,6 +110,11 @@ struct ClusterBuffers {
     // profiling hook (null unless msm_amd_set_pair_trace gave a buffer): per cluster slot the 100 MHz clock at the start
     // and the end of its wave in the list-walking pair kernel, the hardware id of the wave and of its XCD
     unsigned long long *trace;
+    // When set, the pair kernels leave the short-range acceleration of slot s in acc_slots[s] (x, y, z; 32 bytes per slot,
+    // so the 8 particles of a cluster are one contiguous 256-byte block) instead of scattering 24-byte records into the
+    // caller's array by original index; the interpolation kernel, which walks the same slots, then adds the grid part
+    // and does the one scatter into the caller's order.  Null: the pair kernels write the caller's array themselves.
+    double4 *acc_slots;
 };
 void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, int N, const ClusterGeom &g,
                          const ClusterBuffers &b, int *bin_of, int *arrival, int *slot_idx, int *scan_tmp);
@@ -141,6 +146,7 @@ struct TileSrc {
     ClusterGeom cg;      // cluster order only
     int cluster_order;
     double scale[3];     // slot coordinate -> grid units
+    const double4 *acc_slots; // cluster order only, may be null: the short-range accelerations per slot (ClusterBuffers::acc_slots)
 };
 // A/B choices of the tile kernels, kept per handle
 struct SplineOpts {

@@ -470,9 +470,16 @@ __global__ __launch_bounds__(512) void k_interp_tiles(TileSrc S, SplineParams sp
         if (sp.convention == MSM_AMD_ACC_LITERAL) fac = pt.w;
         else if (sp.convention == MSM_AMD_ACC_FORCE) fac = -pt.w;
         const size_t o = 3 * (size_t)orig;
-        acc[o] += fac * gx;
-        acc[o + 1] += fac * gy;
-        acc[o + 2] += fac * gz;
+        if (S.acc_slots) { // the short-range part waits in slot order: one scatter for the sum (the same two terms, the same sum)
+            const double4 sh = S.acc_slots[s];
+            acc[o] = sh.x + fac * gx;
+            acc[o + 1] = sh.y + fac * gy;
+            acc[o + 2] = sh.z + fac * gz;
+        } else {
+            acc[o] += fac * gx;
+            acc[o + 1] += fac * gy;
+            acc[o + 2] += fac * gz;
+        }
     }
 }
 

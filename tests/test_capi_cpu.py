@@ -433,3 +433,29 @@ def test_bench_refuses_more_ranks_than_devices():
     r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0"), capture_output=True,
                        text=True, timeout=120)
     assert r.returncode != 0 and "must agree" in r.stderr and "{" not in r.stdout
+
+
+def test_generated_tables_against_the_reference_header():
+    """include/msm_tables.h is generated from this library's own routines, not transcribed; where /root/reference is
+    present (this container, not the GPU box) its OMEGA and JN entries are held against msm/msmLibrary.h:150-185: the
+    cubic-spline row and JN are the same doubles, the quintic row (which the reference's msmperiodic never reads, p being
+    4 there: msmPeriodic.c:100-104) agrees to a few units in the last place - the two programs factorise the same
+    symbol in a different order of operations."""
+    ref = "/root/reference/msm/msmLibrary.h"
+    if not os.path.exists(ref):
+        pytest.skip("the reference is not on this machine")
+
+    def table(path, name):
+        txt = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+        body = txt[txt.index(name):]
+        body = body[body.index("{"):body.index("};")]
+        return [float(eval(t)) for t in re.findall(r"-?[0-9][0-9.e+\-/]*", body)]
+
+    ours = os.path.join(ROOT, "include", "msm_tables.h")
+    om_r, om_o = np.array(table(ref, "OMEGA[2]")), np.array(table(ours, "OMEGA[2]"))
+    assert om_r.shape == om_o.shape == (28,)
+    assert np.array_equal(om_r[:14], om_o[:14])
+    ulp = np.abs(om_r[14:] - om_o[14:]) / np.spacing(np.abs(om_r[14:]))
+    assert ulp.max() <= 32, ulp
+    jn_r, jn_o = np.array(table(ref, "JN[2]")), np.array(table(ours, "JN[2]"))
+    assert np.array_equal(jn_r, jn_o)
