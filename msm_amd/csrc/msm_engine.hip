@@ -63,6 +63,11 @@ struct msm_amd_handle {
     int nepart = 0;
     double *parts = nullptr; // [grid NPARTS | four NPARTS | charge 2*NPARTS | pair NPARTS]
     double *d_energies = nullptr, *h_energies = nullptr;
+    unsigned *energy_ticket = nullptr; // counter of launch_energy_all
+    int opt_energy_fused = 0;          // 1: partial sums and finishing step in one launch (A/B).  Measured at 1M particles: 24 us against
+                                       // the 18 us of the two launches (the finishing workgroup reads the partial sums of the
+                                       // others past every cache), 60 us when the hand-over is a release / acquire fence pair
+                                       // (each fence writes back and invalidates a chiplet's L2)
     const double *cur_r = nullptr, *cur_q = nullptr;
     // host staging for eval_host
     double *s_r = nullptr, *s_q = nullptr, *s_acc = nullptr, *s_acc2 = nullptr;
@@ -477,6 +482,8 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
     DA(h->epart, std::max(h->nepart, cg.max_clusters));
     DA(h->parts, 5 * NPARTS);
     DA(h->d_energies, MSM_AMD_U_COUNT);
+    DA(h->energy_ticket, 1);
+    HIPCHK_H(hipMemset(h->energy_ticket, 0, sizeof(unsigned)));
     HIPCHK_H(hipHostMalloc((void **)&h->h_energies, MSM_AMD_U_COUNT * sizeof(double), hipHostMallocDefault));
 #undef HIPCHK_H
 #undef DA
@@ -513,7 +520,7 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     for (auto p : h->dKsub) hipFree(p);
     hipFree(h->open_part);
     hipFree(h->efour); hipFree(h->dKL); hipFree(h->dTsum); hipFree(h->dTfour); hipFree(h->tmpA); hipFree(h->tmpB); hipFree(h->epart); hipFree(h->parts);
-    hipFree(h->d_energies);
+    hipFree(h->d_energies); hipFree(h->energy_ticket);
     if (h->h_energies) hipHostFree(h->h_energies);
     hipFree(h->s_r); hipFree(h->s_q); hipFree(h->s_acc); hipFree(h->s_acc2); hipFree(h->conv_part);
     hipFree(h->lit_part_d[0]); hipFree(h->lit_part_d[1]); hipFree(h->lit_part_e);
@@ -576,6 +583,7 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "anterp_cols_waves")) { if (value == 0 || value == 4 || value == 8 || value == 16) { h->sopt.anterp_cols_waves = value; return MSM_AMD_OK; } }
     if (!strcmp(key, "anterp_cols_order4")) { h->sopt.anterp_cols_order4 = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "anterp_cols")) { h->sopt.anterp_cols = value != 0; return MSM_AMD_OK; }
+    if (!strcmp(key, "energy_fused")) { h->opt_energy_fused = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "acc_slots")) { h->opt_acc_slots = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "overlap")) { h->opt_overlap = value; return MSM_AMD_OK; }
     if (!strcmp(key, "slab_own_stream")) { h->opt_slab_own_stream = value != 0; return MSM_AMD_OK; }
@@ -1070,7 +1078,6 @@ static int queue_energies(msm_amd_handle *h, bool raw = false) {
         pa.p_parts = h->parts + 4 * NPARTS;
         in.pair_parts = h->parts + 4 * NPARTS; in.n_pair = NPARTS;
     }
-    launch_energy_partials(h->stream, pa, NPARTS);
     in.grid_parts = pg; in.n_grid = NPARTS;
     in.four_parts = pf; in.n_four = NPARTS;
     in.charge_parts = pc; in.n_charge = NPARTS;
@@ -1078,8 +1085,13 @@ static int queue_energies(msm_amd_handle *h, bool raw = false) {
     in.csr = h->hp.csr;
     in.gamma0_over_a = h->hp.gamma0 / d.a;
     in.literal = h->hp.literal ? 1 : 0;
-    if (raw) launch_raw_sums(h->stream, in, h->d_energies);
-    else launch_finalize_energies(h->stream, in, h->d_energies, h->energies_alias);
+    if (h->opt_energy_fused) {
+        launch_energy_all(h->stream, pa, NPARTS, in, raw, h->d_energies, raw ? nullptr : h->energies_alias, h->energy_ticket);
+    } else {
+        launch_energy_partials(h->stream, pa, NPARTS);
+        if (raw) launch_raw_sums(h->stream, in, h->d_energies);
+        else launch_finalize_energies(h->stream, in, h->d_energies, h->energies_alias);
+    }
     HIPCHK(hipGetLastError());
     return MSM_AMD_OK;
 }

@@ -2152,9 +2152,13 @@ void launch_sum_partials(hipStream_t st, const double *in, int n, double *parts,
     hipLaunchKernelGGL(k_sum_partials, dim3(nparts), dim3(256), 0, st, in, n, parts);
 }
 
+// COHERENT: the values were left by other workgroups of the same launch with device-scope atomic stores; they are read
+// with device-scope atomic loads, which no cache of this compute unit or chiplet serves
+template <bool COHERENT = false>
 __device__ double sum_array(const double *__restrict__ p, int n, double *red) {
     double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) s += p[i];
+    for (int i = threadIdx.x; i < n; i += 256)
+        s += COHERENT ? __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p[i];
     const double t = block_sum<256>(s, red);
     __syncthreads();
     return t;
@@ -2202,14 +2206,15 @@ void launch_energy_partials(hipStream_t st, const EnergyPartialsArgs &a, int npa
     hipLaunchKernelGGL(k_energy_partials, dim3(nparts, 4), dim3(256), 0, st, a);
 }
 
-// (A)..(F) and the total (msmPeriodic.c:1305-1359; msmSimple.c:1968-1969)
-__global__ __launch_bounds__(256) void k_finalize_energies(EnergyInputs in, double *__restrict__ out, double *__restrict__ out2) {
-    __shared__ double red[256];
-    const double ua = sum_array(in.pair_parts, in.n_pair, red);
-    const double qe = sum_array(in.grid_parts, in.n_grid, red);
-    const double qf = sum_array(in.four_parts, in.n_four, red);
-    const double qs = sum_array(in.charge_parts, in.n_charge, red);
-    const double qs2 = sum_array(in.charge_parts + in.n_charge, in.n_charge, red);
+// (A)..(F) and the total (msmPeriodic.c:1305-1359; msmSimple.c:1968-1969) from the partial sums, by one workgroup
+template <bool COHERENT = false>
+__device__ __forceinline__ void finalize_energies(const EnergyInputs &in, double *__restrict__ out, double *__restrict__ out2, double *red,
+                                                  bool pair_parts_coherent = false) {
+    const double ua = (COHERENT && pair_parts_coherent) ? sum_array<true>(in.pair_parts, in.n_pair, red) : sum_array(in.pair_parts, in.n_pair, red);
+    const double qe = sum_array<COHERENT>(in.grid_parts, in.n_grid, red);
+    const double qf = sum_array<COHERENT>(in.four_parts, in.n_four, red);
+    const double qs = sum_array<COHERENT>(in.charge_parts, in.n_charge, red);
+    const double qs2 = sum_array<COHERENT>(in.charge_parts + in.n_charge, in.n_charge, red);
     if (threadIdx.x == 0) {
         double ulr, ulf;
         if (in.literal) { // msmPeriodic.c:1002 (minus sign), :1334-1338 (edir only)
@@ -2231,14 +2236,86 @@ __global__ __launch_bounds__(256) void k_finalize_energies(EnergyInputs in, doub
             for (int k = 0; k < MSM_AMD_U_COUNT; k++) out2[k] = out[k];
     }
 }
+// raw sums for a slab rank: [pair sum, q0.e0 over owned planes, qL.efour, sum q, sum q^2]
+template <bool COHERENT = false>
+__device__ __forceinline__ void raw_sums(const EnergyInputs &in, double *__restrict__ out, double *red, bool pair_parts_coherent = false) {
+    const double ua = (COHERENT && pair_parts_coherent) ? sum_array<true>(in.pair_parts, in.n_pair, red) : sum_array(in.pair_parts, in.n_pair, red);
+    const double qe = sum_array<COHERENT>(in.grid_parts, in.n_grid, red);
+    const double qf = sum_array<COHERENT>(in.four_parts, in.n_four, red);
+    const double qs = sum_array<COHERENT>(in.charge_parts, in.n_charge, red);
+    const double qs2 = sum_array<COHERENT>(in.charge_parts + in.n_charge, in.n_charge, red);
+    if (threadIdx.x == 0) { out[0] = ua; out[1] = qe; out[2] = qf; out[3] = qs; out[4] = qs2; }
+}
+__global__ __launch_bounds__(256) void k_finalize_energies(EnergyInputs in, double *__restrict__ out, double *__restrict__ out2) {
+    __shared__ double red[256];
+    finalize_energies(in, out, out2, red);
+}
 __global__ __launch_bounds__(256) void k_raw_sums(EnergyInputs in, double *__restrict__ out) {
     __shared__ double red[256];
-    const double ua = sum_array(in.pair_parts, in.n_pair, red);
-    const double qe = sum_array(in.grid_parts, in.n_grid, red);
-    const double qf = sum_array(in.four_parts, in.n_four, red);
-    const double qs = sum_array(in.charge_parts, in.n_charge, red);
-    const double qs2 = sum_array(in.charge_parts + in.n_charge, in.n_charge, red);
-    if (threadIdx.x == 0) { out[0] = ua; out[1] = qe; out[2] = qf; out[3] = qs; out[4] = qs2; }
+    raw_sums(in, out, red);
+}
+
+// The partial reductions and the finishing step in ONE launch (a kernel boundary in the dependent chain of an
+// evaluation costs about as much as either of them): every workgroup leaves its partial sum and takes a ticket; the
+// workgroup that draws the last ticket - whichever it is - finishes from the partial sums of all, which it adds in
+// their fixed order, so the result does not depend on who finishes.  Nothing waits for anything: a workgroup that is
+// not the last simply ends.  The partial sums travel as device-scope atomics (an exchange whose return the thread waits
+// for before it takes its ticket; atomic loads on the finishing side), which are performed where every chiplet sees
+// them: a release / acquire fence instead writes back and invalidates the whole L2 of the chiplet, once per workgroup,
+// and made this kernel three times slower than the two launches it replaces.  The ticket counter returns to 0 for the
+// next evaluation (evaluations of one handle are ordered on its stream).
+__device__ __forceinline__ void publish(double *p, double v) {
+    (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(256) void k_energy_all(EnergyPartialsArgs a, EnergyInputs in, int raw, double *__restrict__ out,
+                                                    double *__restrict__ out2, unsigned *__restrict__ ticket) {
+    __shared__ double red[256];
+    __shared__ int last;
+    const int part = blockIdx.x, np = gridDim.x;
+    if (blockIdx.y <= 1) {
+        const double *__restrict__ x = blockIdx.y == 0 ? a.g_q : a.f_q;
+        const double *__restrict__ y = blockIdx.y == 0 ? a.g_e : a.f_e;
+        const size_t n = blockIdx.y == 0 ? a.g_n : a.f_n;
+        double s = 0.0;
+        for (size_t i = (size_t)part * 256 + threadIdx.x; i < n; i += (size_t)np * 256) s = fma(x[i], y[i], s);
+        const double t = block_sum<256>(s, red);
+        if (threadIdx.x == 0) publish((blockIdx.y == 0 ? a.g_parts : a.f_parts) + part, t);
+    } else if (blockIdx.y == 2) {
+        double s = 0.0, s2 = 0.0;
+        for (size_t i = (size_t)part * 256 + threadIdx.x; i < a.c_n; i += (size_t)np * 256) {
+            const double v = a.c_q[i];
+            s += v;
+            s2 = fma(v, v, s2);
+        }
+        const double t = block_sum<256>(s, red);
+        __syncthreads();
+        const double t2 = block_sum<256>(s2, red);
+        if (threadIdx.x == 0) {
+            publish(a.c_parts + part, t);
+            publish(a.c_parts + np + part, t2);
+        }
+    } else if (a.p_parts) { // (a short list of pair partials is summed by the finishing step itself)
+        const int per = (a.p_n + np - 1) / np;
+        const int lo = part * per, hi = min(a.p_n, lo + per);
+        double s = 0.0;
+        for (int i = lo + threadIdx.x; i < hi; i += 256) s += a.p_in[i];
+        const double t = block_sum<256>(s, red);
+        if (threadIdx.x == 0) publish(a.p_parts + part, t);
+    }
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the exchanges above have returned: they are performed
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == gridDim.x * gridDim.y - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    if (raw) raw_sums<true>(in, out, red, a.p_parts != nullptr);
+    else finalize_energies<true>(in, out, out2, red, a.p_parts != nullptr);
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+void launch_energy_all(hipStream_t st, const EnergyPartialsArgs &a, int nparts, const EnergyInputs &in, bool raw, double *out,
+                       double *out_second, unsigned *ticket) {
+    hipLaunchKernelGGL(k_energy_all, dim3(nparts, 4), dim3(256), 0, st, a, in, raw ? 1 : 0, out, out_second, ticket);
 }
 void launch_raw_sums(hipStream_t st, const EnergyInputs &in, double *out5) {
     hipLaunchKernelGGL(k_raw_sums, dim3(1), dim3(256), 0, st, in, out5);

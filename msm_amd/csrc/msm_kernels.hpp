@@ -251,6 +251,10 @@ struct EnergyPartialsArgs {
     const double *p_in; int p_n; double *p_parts;
 };
 void launch_energy_partials(hipStream_t st, const EnergyPartialsArgs &a, int nparts);
+// the same partial sums and the finishing step (launch_finalize_energies, or launch_raw_sums when raw) in one launch:
+// the workgroup that ends last finishes; ticket: one zero-initialised counter in device memory, back at 0 afterwards
+void launch_energy_all(hipStream_t st, const EnergyPartialsArgs &a, int nparts, const EnergyInputs &in, bool raw, double *out,
+                       double *out_second, unsigned *ticket);
 void launch_finalize_energies(hipStream_t st, const EnergyInputs &in, double *out7, double *out7_second = nullptr);
 // raw sums for a slab rank: out5 = [pair sum, q0.e0 over owned planes, qL.efour, sum q, sum q^2]
 void launch_raw_sums(hipStream_t st, const EnergyInputs &in, double *out5);

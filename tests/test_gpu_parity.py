@@ -1190,6 +1190,15 @@ def test_slot_order_accelerations_keep_the_bits(msm, torch, p, conv):
         en_b, acc_b = eng.eval(rd, qd)
         eng.set_option("acc_slots", 1)
         assert np.array_equal(en_a, en_b) and torch.equal(acc_a, acc_b), v
+    # the reductions in one launch (the workgroup that ends last finishes) and in two: the same sums in the same order,
+    # evaluation after evaluation (the ticket counter is back at zero every time)
+    eng.set_option("energy_fused", 1)
+    for _ in range(20):
+        en_f, _ = eng.eval(rd, qd)
+        assert np.array_equal(en_f, en1)
+    eng.set_option("energy_fused", 0)
+    en_t, _ = eng.eval(rd, qd)
+    assert np.array_equal(en_t, en1)
     # stage by stage (the caller's array after every stage)
     acc2 = torch.zeros_like(acc1)
     eng.stage_bin(rd, qd)

@@ -401,7 +401,7 @@ def test_slab_step_options_keep_the_bits(rank):
     cases = [{"slab_overlap": 0}, {"slab_overlap": 1}, {"slab_overlap": 2}, {"slab_overlap": 3}, {"slab_overlap": 4},
              {"conv_tile_planes": 6}, {"conv_tile_planes": 8}, {"conv_tile_planes": 9},
              {"conv_tile_planes": 10}, {"conv_tile_planes": 12, "slab_overlap": 1}, {"pair_wpb": 2}, {"pair_wpb": 4},
-             {"list_wpb": 1}, {"pair_lds_pad": 17408}, {"acc_slots": 0}]
+             {"list_wpb": 1}, {"pair_lds_pad": 17408}, {"acc_slots": 0}, {"energy_fused": 1}]
     for opts in cases:
         acc, sums = _one_rank_steps(rank, world, opts)
         assert torch.equal(acc, ref_acc), opts
