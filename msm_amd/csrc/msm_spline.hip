@@ -70,6 +70,29 @@ __device__ __forceinline__ int launched_tile(const TileGeom &tl, int b) {
     return ((tl.tz0 + layer) % tl.nt[2]) * per + (b - layer * per);
 }
 
+// The z cells [clo, chi] of a tile (cells z0 .. z0 + nzc - 1 of the grid) whose particles can reach a plane the rank owns:
+// a particle in cell c adds to the planes c - p/2 + 1 .. c + p/2, so the cells sp.z0 - p/2 .. sp.z0 + sp.nz - 1 + p/2 - 1
+// count, and one more either side for a particle whose cell and slab were rounded differently.  (A rank holds halo
+// copies out to the cutoff of the pair sum, which is wider.)  Cells that do not count are skipped: their particles add
+// to planes of other ranks only, so the sums of the owned planes keep their terms and their order.  When the cells that
+// count are not one run inside the tile (the range meets itself around the period), all are kept.
+__device__ __forceinline__ void anterp_cells(const SplineParams &sp, int z0, int nzc, int &clo, int &chi) {
+    clo = 0;
+    chi = nzc - 1;
+    const int Mz = sp.M[2], len = sp.nz + sp.p + 1;
+    if (sp.nz >= Mz || len >= Mz) return;
+    const int lo = modp(sp.z0 - sp.p / 2 - 1, Mz);
+    int first = -1, lastc = -1, nin = 0;
+    for (int c = 0; c < nzc; c++) {
+        const bool in = modp(z0 + c - lo, Mz) < len;
+        if (in) { if (first < 0) first = c; lastc = c; nin++; }
+    }
+    if (nin == 0) { clo = 0; chi = -1; return; }
+    if (lastc - first + 1 != nin) return;
+    clo = first;
+    chi = lastc;
+}
+
 template <int P>
 __global__ __launch_bounds__(256) void k_anterp_tiles(TileSrc S, SplineParams sp, TileGeom tl, double *__restrict__ scratch,
                                                       int *__restrict__ tile_used) {
@@ -84,12 +107,20 @@ __global__ __launch_bounds__(256) void k_anterp_tiles(TileSrc S, SplineParams sp
     const int x0 = tx * AT, y0 = ty * AT, z0 = tz * AT;
     const int nxc = min(AT, Mx - x0), nyc = min(AT, My - y0), nzc = min(AT, Mz - z0);
     const int nruns = tile_runs(S, nxc, nyc, nzc);
+    // cluster order: only the z cells whose particles reach the rank's planes (runs are columns, sorted by z)
+    int zr0 = z0, nzr = nzc;
+    if (S.cluster_order) {
+        int clo, chi;
+        anterp_cells(sp, z0, nzc, clo, chi);
+        zr0 = z0 + clo;
+        nzr = chi - clo + 1;
+    }
     // an empty tile (most tiles of a slab rank) is only flagged; the combine kernel then skips its block
     if (threadIdx.x == 0) any_particle = 0;
     __syncthreads();
-    if ((int)threadIdx.x < nruns) {
+    if ((int)threadIdx.x < nruns && nzr > 0) {
         int first, cnt;
-        tile_run(S, sp, x0, y0, z0, nxc, nyc, nzc, threadIdx.x, first, cnt);
+        tile_run(S, sp, x0, y0, zr0, nxc, nyc, nzr, threadIdx.x, first, cnt);
         if (cnt > 0) any_particle = 1;
     }
     __syncthreads();
@@ -110,7 +141,7 @@ __global__ __launch_bounds__(256) void k_anterp_tiles(TileSrc S, SplineParams sp
     const int lane_off = (c * R + b) * R + a;
     for (int run = wave; run < nruns; run += 4) {
         int s0, n;
-        tile_run(S, sp, x0, y0, z0, nxc, nyc, nzc, run, s0, n);
+        tile_run(S, sp, x0, y0, zr0, nxc, nyc, nzr, run, s0, n);
         for (int sb = 0; sb < n; sb += 64) {
             const int cnt = min(64, n - sb);
             // every lane prepares one particle of the batch: cell, offset inside the cell, and (p = 6) the six
@@ -176,11 +207,13 @@ __global__ __launch_bounds__(1024) void k_anterp_cols(TileSrc S, SplineParams sp
     // all the bookkeeping of the tile's runs up front, one (run, z cell) per thread: the waves then never wait for
     // a chain of dependent index loads between two runs
     const int nw = blockDim.x >> 6; // waves of the workgroup: 4 to 16, one run each at a time
+    int clo, chi; // z cells of the tile whose particles reach the rank's planes: the others get empty ranges
+    anterp_cells(sp, z0, nzc, clo, chi);
     for (int t = threadIdx.x; t < nruns * (AT + 1); t += blockDim.x) {
-        const int run = t / (AT + 1), c = t % (AT + 1);
+        const int run = t / (AT + 1), c = min(max(t % (AT + 1), clo), chi + 1);
         const int col = cl_col(S.cg, x0 / KX + run % ncxt, y0 / KY + run / ncxt), bb = col * nzf;
         // slot of a particle = CL_G * (first cluster of its column) + its rank inside the column
-        sbnd[run][c] = CL_G * S.clstart[col] - S.start[bb] + S.start[bb + (z0 + min(c, nzc)) * kz];
+        sbnd[run][t % (AT + 1)] = CL_G * S.clstart[col] - S.start[bb] + S.start[bb + (z0 + min(c, nzc)) * kz];
     }
     __syncthreads();
     if ((int)threadIdx.x < nruns && sbnd[threadIdx.x][AT] > sbnd[threadIdx.x][0]) any_particle = 1;
