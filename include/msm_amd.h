@@ -256,6 +256,11 @@ int msm_amd_plan_auto(int N, double Ax, double Ay, double Az, int p, int mu, dou
 int msm_amd_plan_open(int N, const double lo[3], const double hi[3], int p, int mu, double h, double a, int L,
                       msm_amd_plan_desc *out);
 
+/* 1 when the open-boundary plan *plan still serves particles inside the box [lo, hi] (they moved): the box lies inside
+ * the padded cell, (p/2 + 1) grid spacings clear of its faces, and the cell leaves the room msm_amd_plan_open would give
+ * a box of this extent; 0 otherwise (make a new plan).  No counterpart in the reference. */
+int msm_amd_plan_open_holds(const msm_amd_plan_desc *plan, const double lo[3], const double hi[3]);
+
 typedef struct msm_amd_handle msm_amd_handle;
 
 /* Builds omega', all stencils (position independent; see msm_amd_set_stencil_backend) and allocates every device buffer.
@@ -298,6 +303,9 @@ int msm_amd_stage_energies(msm_amd_handle *h, double *energies);
 /* ---- slab ranks (one process per GPU; collectives are the caller's) ---- */
 /* particles of the next evaluation: n_total <= plan N (the capacity), the first n_owned of them owned */
 int msm_amd_set_counts(msm_amd_handle *h, int n_total, int n_owned);
+/* the level-0 z planes [zplane0, zplane0 + nzplanes) the rank owns from the next evaluation on (the slabs of an
+ * open-boundary plan are cut where the particles are, so they move with them); the buffers keep their size */
+int msm_amd_set_planes(msm_amd_handle *h, int zplane0, int nzplanes);
 /* [pair sum, q0.e0 over owned planes, qL.efour, sum q, sum q^2 over owned particles]: additive over ranks
  * (except the third, which is replicated).  Left on the device; host_out5 != NULL copies them back. */
 int msm_amd_stage_raw_sums(msm_amd_handle *h, double *host_out5);

@@ -128,6 +128,8 @@ SIGNATURES = {
     "msm_amd_stage_interpolate": (C.c_int, [_vp, _vp]),
     "msm_amd_stage_energies": (C.c_int, [_vp, _dp]),
     "msm_amd_set_counts": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "msm_amd_set_planes": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "msm_amd_plan_open_holds": (C.c_int, [C.POINTER(PlanDesc), _dp, _dp]),
     "msm_amd_stage_raw_sums": (C.c_int, [_vp, _dp]),
     "msm_amd_raw_sums_device_ptr": (_vp, [_vp]),
     "msm_amd_combine_energies": (C.c_int, [_vp, _dp, _dp]),

@@ -556,6 +556,19 @@ extern "C" int msm_amd_set_counts(msm_amd_handle *h, int n_total, int n_owned) {
     return MSM_AMD_OK;
 }
 
+extern "C" int msm_amd_set_planes(msm_amd_handle *h, int zplane0, int nzplanes) {
+    if (!h || zplane0 < 0 || nzplanes < 1 || zplane0 + nzplanes > h->hp.d.M[2]) {
+        set_error("set_planes: need 0 <= zplane0, 1 <= nzplanes, zplane0 + nzplanes <= %d", h ? h->hp.d.M[2] : 0);
+        return MSM_AMD_EINVAL;
+    }
+    if (h->small_box && nzplanes != h->hp.d.M[2]) { set_error("set_planes: slab decomposition needs at least 3 pair cells per axis"); return MSM_AMD_EINVAL; }
+    h->hp.d.zplane0 = zplane0;
+    h->hp.d.nzplanes = nzplanes;
+    h->sp.z0 = zplane0;
+    h->sp.nz = nzplanes;
+    return MSM_AMD_OK;
+}
+
 extern "C" void msm_amd_set_profiling(msm_amd_handle *h, int on) {
     if (!h) return;
     hipSetDevice(h->device);

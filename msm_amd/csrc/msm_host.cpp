@@ -679,6 +679,30 @@ int msm_amd_plan_auto(int N, double Ax, double Ay, double Az, int p, int mu, dou
     return MSM_AMD_OK;
 }
 
+// room an open-boundary cell needs beyond a particle box of extent Ek with `levels` levels (hc = coarsest spacing):
+//   coarsest level: grid charges and needed potentials reach (p/2) hc beyond the particles, plus a node of slack;
+//   level L-2: they reach (p/2) h_{L-2} and its stencil 2^(L-1) a, which must not meet across the wrap;
+//   the pair sum wants at least three cutoffs per axis.
+static double open_room(int p, double h, double a, int levels, double Ek) {
+    const double hc = std::ldexp(h, levels - 1);
+    double need = std::max((p + 2) * hc, a + 2 * h); // (no pair may come within the cutoff through the wrap either)
+    if (levels >= 2) need = std::max(need, (p / 2) * hc + std::ldexp(a, levels - 1) + 2 * h);
+    return std::max(need, 3.05 * a - Ek);
+}
+
+int msm_amd_plan_open_holds(const msm_amd_plan_desc *d, const double lo[3], const double hi[3]) {
+    if (!d || !lo || !hi || !d->open_boundary) return 0;
+    for (int k = 0; k < 3; k++) {
+        const double h = d->A[k] / d->M[k], E = hi[k] - lo[k];
+        if (!(E >= 0)) return 0;
+        // inside the cell, clear of its faces by the reach of a spline support and a node (slabs are cut without wrap-around)
+        const double margin = (d->p / 2 + 1) * h;
+        if (lo[k] < d->origin[k] + margin || hi[k] > d->origin[k] + d->A[k] - margin) return 0;
+        if (d->A[k] - E < open_room(d->p, h, d->a, d->L, E)) return 0;
+    }
+    return 1;
+}
+
 int msm_amd_plan_open(int N, const double lo[3], const double hi[3], int p, int mu, double h, double a, int L,
                       msm_amd_plan_desc *o) {
     if (!o || !lo || !hi || N < 1 || !(h > 0) || !(a > 0) || (p != 4 && p != 6)) {
@@ -691,16 +715,7 @@ int msm_amd_plan_open(int N, const double lo[3], const double hi[3], int p, int 
         if (!(E[k] >= 0)) { msm::set_error("msm_amd_plan_open: hi < lo"); return MSM_AMD_EINVAL; }
         Emax = std::max(Emax, E[k]);
     }
-    // room the cell needs beyond the particles' box with L levels (hc = coarsest spacing):
-    //   coarsest level: grid charges and needed potentials reach (p/2) hc beyond the particles, plus a node of slack;
-    //   level L-2: they reach (p/2) h_{L-2} and its stencil 2^(L-1) a, which must not meet across the wrap;
-    //   the pair sum wants at least three cutoffs per axis.
-    auto room = [&](int levels, double Ek) {
-        const double hc = std::ldexp(h, levels - 1);
-        double need = std::max((p + 2) * hc, a + 2 * h); // (no pair may come within the cutoff through the wrap either)
-        if (levels >= 2) need = std::max(need, (p / 2) * hc + std::ldexp(a, levels - 1) + 2 * h);
-        return std::max(need, 3.05 * a - Ek);
-    };
+    auto room = [&](int levels, double Ek) { return open_room(p, h, a, levels, Ek); };
     if (L <= 0) { // deepest hierarchy whose coarsest grid still has 8 nodes on the longest axis, at most 32 on it
         L = 1;
         while (L < LMAX && (Emax + room(L, Emax)) / std::ldexp(h, L - 1) > 32.0) L++;

@@ -34,6 +34,13 @@ def plan_open(N, lo, hi, p, mu, h, a, L=0):
     return d
 
 
+def plan_open_holds(desc, lo, hi):
+    """True while the open-boundary plan `desc` still serves particles inside the box [lo, hi] (msm_amd_plan_open_holds)."""
+    lo3 = (C.c_double * 3)(*[float(x) for x in lo])
+    hi3 = (C.c_double * 3)(*[float(x) for x in hi])
+    return bool(load().msm_amd_plan_open_holds(C.byref(desc), lo3, hi3))
+
+
 def plan_explicit(N, A, M, p, mu, L, a, beta, kmax, acc_convention=capi.ACC_GRADIENT):
     d = PlanDesc()
     d.N, d.p, d.mu, d.L, d.kmax, d.acc_convention = int(N), int(p), int(mu), int(L), int(kmax), int(acc_convention)
@@ -186,6 +193,10 @@ class Engine:
     def set_counts(self, n_total, n_owned):
         check(load().msm_amd_set_counts(self._h, int(n_total), int(n_owned)), "set_counts")
         self.N = int(n_total)
+
+    def set_planes(self, zplane0, nzplanes):
+        check(load().msm_amd_set_planes(self._h, int(zplane0), int(nzplanes)), "set_planes")
+        self.desc.zplane0, self.desc.nzplanes = int(zplane0), int(nzplanes)
 
     def stage_raw_sums(self):
         """Queue the raw sums [pair, q0.e0 (owned planes), qL.efour, sum q, sum q^2]; they stay on the device."""

@@ -268,17 +268,32 @@ def select_slab(r, Az, Mz, world, rank, halo):
     return np.nonzero(owned)[0], np.nonzero(halo_mask)[0]
 
 
-def open_slab_edges(r, desc, world):
-    """Plane boundaries e[0] = 0 <= e[1] <= ... <= e[world] = Mz of an open-boundary plan, cut so that every rank owns
-    about the same number of particles (the cell is padded: planes at either end hold none).  Deterministic in the
-    positions, so every rank computes the same cut."""
-    Mz = desc.M[2]
-    zg = (np.asarray(r)[:, 2] - desc.origin[2]) / desc.A[2] * Mz      # grid units
-    cuts = np.quantile(zg, np.arange(1, world) / world)
-    e = [0] + [int(round(c)) for c in cuts] + [Mz]
-    for k in range(1, world):                                          # strictly increasing, at least one plane each
+def open_plane_counts(zg, Mz):
+    """Particles per level-0 plane (numpy): plane = floor of the grid coordinate, clamped to the grid."""
+    plane = np.clip(np.floor(np.asarray(zg)).astype(np.int64), 0, Mz - 1)
+    return np.bincount(plane, minlength=Mz).astype(np.int64)
+
+
+def open_edges_from_counts(counts, world):
+    """Plane boundaries e[0] = 0 <= e[1] <= ... <= e[world] = Mz from the particle counts per plane: e[k] is the first
+    plane boundary with at least k / world of the particles below it, then made strictly increasing (at least one plane
+    each).  A function of the counts alone: ranks that hold the all-reduced counts compute the same cut."""
+    counts = np.asarray(counts, dtype=np.int64)
+    Mz, total = len(counts), int(counts.sum())
+    below = np.concatenate([[0], np.cumsum(counts)])          # below[j]: particles in planes < j
+    e = [0] + [int(np.searchsorted(below, -(-k * total // world), side="left")) for k in range(1, world)] + [Mz]
+    for k in range(1, world):
         e[k] = min(max(e[k], e[k - 1] + 1), Mz - (world - k))
     return e
+
+
+def open_slab_edges(r, desc, world):
+    """Plane boundaries of an open-boundary plan, cut so that every rank owns about the same number of particles (the
+    cell is padded: planes at either end hold none).  Deterministic in the positions, so every rank computes the same
+    cut; SlabRank.exchange() recomputes it from all-reduced plane counts by the same rule."""
+    Mz = desc.M[2]
+    zg = (np.asarray(r)[:, 2] - desc.origin[2]) / desc.A[2] * Mz      # grid units
+    return open_edges_from_counts(open_plane_counts(zg, Mz), world)
 
 
 def select_open_slab(r, desc, edges, rank, halo):
@@ -298,6 +313,10 @@ def halo_width(desc, margin=0.0):
     return max(desc.a, (desc.p / 2) * hz) + margin
 
 
+class PlanOutgrown(RuntimeError):
+    """SlabRank.exchange(): the particles have left the padded cell of an open-boundary plan."""
+
+
 class SlabRank:
     """One rank of a slab-decomposed evaluation.  `engine_factory(desc)` returns an object with the Engine
     interface (tests inject a CPU stand-in to exercise the partition and collective logic without a GPU).
@@ -310,6 +329,7 @@ class SlabRank:
     def __init__(self, torch, dist, msm_amd, desc, r_all, q_all, rank, world, local_rank=0, margin=2e-4,
                  engine_factory=None, perturb=False, headroom=1.02, mode=capi.SLAB_AUTO, collectives=None, c_step=True):
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+        self.desc = desc
         self.open = bool(getattr(desc, "open_boundary", 0))
         if self.open:
             # slabs cut by particle count; the level-0 charges are summed over the ranks (msm_amd_slab_step)
@@ -381,29 +401,65 @@ class SlabRank:
         caller; halo rows are ignored).  Ownership and halo membership follow select_slab's expressions on the new
         positions; every rank sends each of its owned particles to the new owner and to every rank whose halo it
         falls in, owned records before halo records, so a receiver holds [owned from rank 0, 1, ... | halo from rank
-        0, 1, ...].  Two collectives: all-to-all of the counts, all-to-all of the records."""
-        if self.open:
-            raise ValueError("SlabRank.exchange() is for periodic plans: an open-boundary plan is rebuilt around the new "
-                             "positions (msm_amd_plan_open), which moves the slab cuts too")
+        0, 1, ...].  Two collectives: all-to-all of the counts, all-to-all of the records.  An open-boundary plan adds two
+        all-reduces in front (bounding box, particles per plane) and cuts its slabs again; it raises PlanOutgrown when the
+        particles no longer fit the plan's padded cell."""
         t, W = self.torch, self.world
         n = self.n_own
         r, q, gid = self.r[:n], self.q[:n], self.gid[:n]
-        zf = r[:, 2] / self.Az
-        zf = zf - t.floor(zf)
-        edges = t.arange(W + 1, dtype=t.float64, device=r.device) / W   # k / W: the bounds select_slab compares with
-        owner = t.clamp(t.bucketize(zf, edges, right=True) - 1, 0, W - 1)
-        hf = self.halo / self.Az
         rec = t.cat([r, q[:, None], gid.to(t.float64)[:, None]], dim=1)   # global indices below 2^53 are exact
         own_parts, halo_parts, counts = [], [], t.zeros((W, 2), dtype=t.int64)
-        for k in range(W):
-            lo, hi = edges[k], edges[k + 1]
-            mine = owner == k
-            below = t.remainder(lo - zf, 1.0)
-            above = t.remainder(zf - hi, 1.0)
-            halo = (~mine) & ((below <= hf) | (above < hf))
-            own_parts.append(rec[mine])
-            halo_parts.append(rec[halo])
-            counts[k, 0], counts[k, 1] = int(mine.sum()), int(halo.sum())
+        if self.open:
+            # Open boundaries: the padded cell stays while the particles' bounding box stays inside it
+            # (msm_amd_plan_open_holds), and the slabs are cut again where the particles now are - by the rule of
+            # open_slab_edges, from plane counts added over the ranks - so the owned planes of a rank move too.
+            d = self.desc
+            Mz = d.M[2]
+            big = 1e300
+            lo3 = r.min(dim=0).values if n else t.full((3,), big, dtype=t.float64, device=r.device)
+            hi3 = r.max(dim=0).values if n else t.full((3,), -big, dtype=t.float64, device=r.device)
+            zg = (r[:, 2] - d.origin[2]) / d.A[2] * Mz
+            pc = t.bincount(t.clamp(t.floor(zg), 0, Mz - 1).to(t.int64), minlength=Mz)
+            cdev = "cpu" if self._host_staged() or self.dist.get_backend() == "gloo" else r.device
+            box = t.cat([-lo3, hi3]).to(cdev)
+            pc = pc.to(cdev)
+            self.dist.all_reduce(box, op=self.dist.ReduceOp.MAX)
+            self.dist.all_reduce(pc)
+            box = box.cpu().numpy()
+            lo_all, hi_all = -box[:3], box[3:]
+            if not self._plan_holds(lo_all, hi_all):
+                raise PlanOutgrown("the particles' bounding box [%s, %s] has left the padded cell of the open-boundary plan: make a "
+                                   "new plan around them (msm_amd_plan_open) and a new SlabRank" % (lo_all, hi_all))
+            self.edges = open_edges_from_counts(pc.cpu().numpy(), W)
+            inner = t.as_tensor(np.asarray(self.edges[1:-1], dtype=np.float64), device=r.device)
+            owner = t.clamp(t.bucketize(zg, inner, right=True), 0, W - 1)     # = searchsorted(..., side="right") of select_open_slab
+            hg = self.halo / d.A[2] * Mz
+            for k in range(W):
+                mine = owner == k
+                halo = (~mine) & (zg >= self.edges[k] - hg) & (zg < self.edges[k + 1] + hg)
+                own_parts.append(rec[mine])
+                halo_parts.append(rec[halo])
+                counts[k, 0], counts[k, 1] = int(mine.sum()), int(halo.sum())
+            z0, nz = self.edges[self.rank], self.edges[self.rank + 1] - self.edges[self.rank]
+            if (z0, nz) != (self.z0, self.nz):
+                self.eng.set_planes(z0, nz)
+                self.z0, self.nz = z0, nz
+                self.send = t.empty_like(self.q0[self.z0:self.z0 + self.nz])
+        else:
+            zf = r[:, 2] / self.Az
+            zf = zf - t.floor(zf)
+            edges = t.arange(W + 1, dtype=t.float64, device=r.device) / W   # k / W: the bounds select_slab compares with
+            owner = t.clamp(t.bucketize(zf, edges, right=True) - 1, 0, W - 1)
+            hf = self.halo / self.Az
+            for k in range(W):
+                lo, hi = edges[k], edges[k + 1]
+                mine = owner == k
+                below = t.remainder(lo - zf, 1.0)
+                above = t.remainder(zf - hi, 1.0)
+                halo = (~mine) & ((below <= hf) | (above < hf))
+                own_parts.append(rec[mine])
+                halo_parts.append(rec[halo])
+                counts[k, 0], counts[k, 1] = int(mine.sum()), int(halo.sum())
         send = t.cat([x for k in range(W) for x in (own_parts[k], halo_parts[k])], dim=0)
         staged = self._host_staged()
         cdev = "cpu" if staged or self.dist.get_backend() == "gloo" else r.device
@@ -437,6 +493,10 @@ class SlabRank:
         self.eng.set_counts(n_tot, n_own)
         if self.perturb:
             self._make_position_sets()
+
+    def _plan_holds(self, lo, hi):
+        from . import engine
+        return engine.plan_open_holds(self.desc, lo, hi)
 
     def _host_staged(self):
         # a gloo group cannot move device memory: stage through the host (functional testing on one GPU)

@@ -523,3 +523,84 @@ def test_rank_of_eight_at_ten_million_tall_tiles():
     scale = float(res[0][0].abs().max())
     assert float((res[0][0] - res[8][0]).abs().max()) <= 1e-12 * scale
     assert float(((res[0][1] - res[8][1]).abs() / res[0][1].abs().clamp_min(1e-300)).max()) <= 1e-11
+
+
+OPEN_PAD = 0.2
+
+
+def _moved_open(r):
+    """Displacements that carry particles across the slab cuts and shift the cloud as a whole, inside the plan's padding."""
+    i = np.arange(len(r))
+    return r + np.stack([0.02 * np.cos(0.7 * i), 0.03 * np.sin(1.3 * i), 0.04 + 0.1 * np.sin(0.37 * i)], axis=1)
+
+
+def _open_exchange_worker(rank, world, port, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)
+    import torch
+    import torch.distributed as dist
+    import msm_amd
+    from msm_amd.slab import SlabRank, PlanOutgrown
+    from test_gpu_parity import open_system
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, p, mu, h, a, L = OPEN_SLAB
+    r, q = open_system(N, 5, (1.0, 0.8, 1.3), (0.3, -0.2, 5.0))
+    desc = msm_amd.plan_open(N, r.min(axis=0) - OPEN_PAD, r.max(axis=0) + OPEN_PAD, p, mu, h, a, L)   # room for the particles to move
+    sr = SlabRank(torch, dist, msm_amd, desc, r, q, rank, world, local_rank=0, headroom=1.4)
+    sr.step()
+    before = (sr.z0, sr.nz)
+    rn = _moved_open(r)
+    sr.r[:sr.n_own] = torch.as_tensor(rn[sr.own_idx], device=sr.r.device)
+    sr.exchange()
+    en = sr.step()
+    # and a move that leaves the padded cell is refused on every rank alike
+    far = sr.r.clone()
+    far[:sr.n_own, 2] += 3.0 * (sr.gid[:sr.n_own] % 2).to(torch.float64)
+    keep = sr.r
+    sr.r = far
+    refused = False
+    try:
+        sr.exchange()
+    except PlanOutgrown:
+        refused = True
+    sr.r = keep
+    np.savez(os.path.join(out_dir, "oex%d.npz" % rank), en=en, idx=sr.own_idx, acc=sr.owned_acc().cpu().numpy(), z0=sr.z0, nz=sr.nz,
+             z0_before=before[0], nz_before=before[1], refused=refused)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_open_boundary_exchange_on_gpu(tmp_path):
+    """SlabRank.exchange() of an open-boundary plan (msm3d, msm/msmLibrary.h:216): the particles move inside the plan's
+    padded cell, the slabs are cut again where they now are (the owned planes of the ranks change), particles migrate
+    and the halos are rebuilt; four ranks sharing cuda:0 then reproduce the one-GPU evaluation of the new positions with
+    the same plan.  Particles that leave the cell make every rank raise PlanOutgrown."""
+    import torch.multiprocessing as mp
+    import msm_amd
+    from test_gpu_parity import open_system
+    world = 4
+    mp.spawn(_open_exchange_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    N, p, mu, h, a, L = OPEN_SLAB
+    r, q = open_system(N, 5, (1.0, 0.8, 1.3), (0.3, -0.2, 5.0))
+    desc = msm_amd.plan_open(N, r.min(axis=0) - OPEN_PAD, r.max(axis=0) + OPEN_PAD, p, mu, h, a, L)
+    rn = _moved_open(r)
+    assert msm_amd.plan_open_holds(desc, rn.min(axis=0), rn.max(axis=0))
+    eng = msm_amd.Engine(desc)
+    en1, acc1 = eng.eval(rn, q)
+    acc1 = acc1.cpu().numpy()
+    acc = np.zeros((N, 3))
+    seen = np.zeros(N, dtype=int)
+    scale = np.abs(en1[:6]).max()
+    planes, recut = 0, False
+    for k in range(world):
+        z = np.load(os.path.join(str(tmp_path), "oex%d.npz" % k))
+        acc[z["idx"]] = z["acc"]
+        seen[z["idx"]] += 1
+        assert int(z["z0"]) == planes and bool(z["refused"])
+        planes += int(z["nz"])
+        recut = recut or (int(z["z0"]), int(z["nz"])) != (int(z["z0_before"]), int(z["nz_before"]))
+        assert np.abs(z["en"] - en1).max() < 1e-12 * scale, (k, z["en"], en1)
+    assert planes == desc.M[2] and (seen == 1).all() and recut
+    assert np.sqrt(((acc - acc1) ** 2).sum() / (acc1 ** 2).sum()) < 1e-12

@@ -329,3 +329,97 @@ def test_rccl_negotiation_keeps_the_ranks_together(tmp_path):
         if fail and fail[0] == "create":        # the rank whose communicator came up gave it back
             other = 1 - fail[1]
             assert res[other][i]["closed"] and not res[fail[1]][i]["closed"]
+
+
+class _PlanesOnlyEngine:
+    """Stand-in with just what SlabRank's constructor and exchange() touch (no stages): the partition logic of an
+    open-boundary plan runs without a GPU."""
+
+    def __init__(self, d):
+        import torch
+        self.torch, self.d = torch, d
+        self.planes = (d.zplane0, d.nzplanes)
+        self.q0 = torch.zeros((d.M[2], 2, 2), dtype=torch.float64)
+
+    def tensor_device(self):
+        return "cpu"
+
+    def set_counts(self, n_total, n_owned):
+        self.counts = (n_total, n_owned)
+
+    def set_planes(self, z0, nz):
+        self.planes = (z0, nz)
+
+    def grid_tensor(self, which, level=0):
+        return self.q0
+
+    def raw_sums_tensor(self):
+        return self.torch.zeros(5, dtype=self.torch.float64)
+
+
+def _open_partition_worker(rank, world, port, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(60, exit=True)
+    import torch
+    import torch.distributed as dist
+    import msm_amd
+    from msm_amd.slab import SlabRank, PlanOutgrown
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    r, q, desc, rn = _open_partition_case(msm_amd)
+    sr = SlabRank(torch, dist, msm_amd, desc, r, q, rank, world, engine_factory=_PlanesOnlyEngine, headroom=1.5)
+    sr._plan_holds = lambda lo, hi: bool(np.all(lo > np.array(desc.origin)) and np.all(hi < np.array(desc.origin) + np.array(desc.A)))
+    sr.r[:sr.n_own] = torch.as_tensor(rn[sr.own_idx])
+    sr.exchange()
+    refused = False
+    sr.r[:sr.n_own, 2] += 100.0
+    try:
+        sr.exchange()
+    except PlanOutgrown:
+        refused = True
+    np.savez(os.path.join(out_dir, "op%d.npz" % rank), own=sr.own_idx, halo=sr.halo_idx, edges=np.array(sr.edges), planes=np.array(sr.eng.planes),
+             counts=np.array(sr.eng.counts), refused=refused)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _open_partition_case(msm_amd):
+    rng = np.random.default_rng(9)
+    N = 6000
+    r = rng.random((N, 3)) * np.array([1.0, 0.8, 1.3]) + np.array([0.3, -0.2, 5.0])
+    r[: N // 2, 2] = 5.0 + 0.3 * rng.random(N // 2)          # half of the particles in the lowest quarter: uneven slabs
+    q = np.where(np.arange(N) % 2 == 0, 1.0, -1.0)
+    desc = msm_amd.capi.PlanDesc()
+    desc.N, desc.p, desc.mu, desc.L, desc.open_boundary = N, 6, 10, 3, 1
+    for k, (m, a0, o) in enumerate(zip((64, 56, 72), (2.0, 1.75, 2.25), (-0.2, -0.7, 4.5))):
+        desc.M[k], desc.A[k], desc.origin[k] = m, a0, o
+    desc.a, desc.zplane0, desc.nzplanes = 0.125, 0, 72
+    i = np.arange(N)
+    rn = r + np.stack([0.02 * np.cos(0.7 * i), 0.03 * np.sin(1.3 * i), 0.05 + 0.2 * np.sin(0.37 * i)], axis=1)
+    return r, q, desc, rn
+
+
+def test_open_boundary_exchange_partition(tmp_path):
+    """SlabRank.exchange() of an open-boundary plan over three gloo ranks (no GPU: a stand-in engine that records the
+    planes and counts it is given): after the particles moved, the slabs are cut again from the all-reduced plane counts,
+    every particle is owned exactly once, owned and halo sets are what select_open_slab gives for the new positions and
+    the new cut, the engine is told its new planes, and a cloud that leaves the cell is refused on every rank."""
+    import torch.multiprocessing as mp
+    import msm_amd
+    from msm_amd import slab
+    world = 3
+    mp.spawn(_open_partition_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r, q, desc, rn = _open_partition_case(msm_amd)
+    edges = slab.open_slab_edges(rn, desc, world)
+    assert edges != slab.open_slab_edges(r, desc, world)
+    seen = np.zeros(len(q), dtype=int)
+    for k in range(world):
+        z = np.load(os.path.join(str(tmp_path), "op%d.npz" % k))
+        assert list(z["edges"]) == edges and bool(z["refused"])
+        own, hal = slab.select_open_slab(rn, desc, edges, k, slab.halo_width(desc))
+        assert set(z["own"]) == set(own) and set(z["halo"]) == set(hal)
+        assert tuple(z["planes"]) == (edges[k], edges[k + 1] - edges[k])
+        assert tuple(z["counts"]) == (len(own) + len(hal), len(own))
+        seen[z["own"]] += 1
+    assert (seen == 1).all()
