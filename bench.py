@@ -22,6 +22,9 @@ forwards rank 0's JSON line and exits non-zero if any rank did.  Under torch.dis
 WORLD_SIZE.  N ranks need N devices: the run fails otherwise instead of measuring fewer (MSM_AMD_BENCH_BACKEND=gloo is a
 functional rehearsal with ranks sharing devices and is labelled as such in the line).
 
+`list_reuse` in the line is a separate measurement of msm_amd_eval_reuse (neighbour lists kept between evaluations) on the
+same steps; it is never `value`.
+
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_pair_clusters_filtered, the short-range pair
 sum): algorithmic flops (ordered in-cutoff pairs x 34 flop at p=4 / 42 at p=6) over that kernel's mean
 duration, measured with a pair of HIP events recorded around it on the stream it runs on.  `traffic` is the
@@ -78,6 +81,8 @@ def main():
     ap.add_argument("--pair-variant", type=int, default=-1)
     ap.add_argument("--no-accuracy", action="store_true", help="skip the Ewald reference (error of the MSM result)")
     ap.add_argument("--opts", default="", help="engine options for A/B runs, key=value,key=value (msm_amd_set_option)")
+    ap.add_argument("--no-list-reuse", action="store_true", help="skip the separate msm_amd_eval_reuse measurement")
+    ap.add_argument("--reuse-skin", type=float, default=0.05, help="skin of the list-reuse measurement, in units of the cutoff a")
     ap.add_argument("--reference-binary", action="store_true",
                     help="cpu_baseline: also run the real msmPeriodic (oracle/_ref, when it was built) at N = 8 and 64 (about 10 s)")
     ap.add_argument("--literal-n", type=int, default=0,
@@ -187,6 +192,17 @@ def main():
     nprof = max(3, min(10, args.steps))
     acc_ms = stepper.profile(nprof)
 
+    # A separate measurement, never `value`: the same steps through msm_amd_eval_reuse, which keeps its neighbour lists
+    # (built with cutoff a + skin) while no particle has moved more than skin / 2 - checked on the device in every call.
+    reuse = None
+    if world == 1 and not args.no_list_reuse:
+        reuse = stepper.measure_reuse(args.reuse_skin * desc.a, args.warmup, args.steps, nprof)
+        reuse["skin_over_a"] = args.reuse_skin
+        ps = reuse.get("pair_kernel_ms", 0.0) * 1e-3
+        if ps > 0:
+            reuse["pair_kernel_tflops"] = N * (4.0 * math.pi / 3.0) * abar ** 3 * FLOP_PER_PAIR[p] / ps / 1e12
+            reuse["pair_kernel_frac_of_peak"] = reuse["pair_kernel_tflops"] / FP64_PEAK_TFLOPS
+
     # ordered in-cutoff pairs handled by one launch (of rank 0): its owned particles x the neighbours within the cutoff
     pairs = (stepper.n_own if world > 1 else N) * (4.0 * math.pi / 3.0) * abar ** 3
     flops = pairs * FLOP_PER_PAIR[p]
@@ -253,6 +269,7 @@ def main():
                                  "N*(4pi/3)*abar^3 ordered pairs x %d flop" % FLOP_PER_PAIR[p]},
             "kernel_ms": acc_ms,
             **({"multi_gpu": multi} if multi is not None else {}),
+            **({"list_reuse": reuse} if reuse is not None else {}),
             "energies_last_timed_step": dict(zip(capi.U_NAMES, [float(x) for x in energies])) if energies is not None else None,
             "energies_note": "of the last timed step, whose positions are the benchmark system displaced by up to 5e-5; the "
                              "unperturbed system is the one in `parity` and `accuracy`",
@@ -382,6 +399,51 @@ class SingleGpu:
     def eval_unperturbed(self):
         en, acc = self.eng.eval(self.r, self.q, self.acc)
         return np.array(en), acc.cpu().numpy().copy()
+
+    def measure_reuse(self, skin, warmup, steps, nprof):
+        """The same displaced copies of the system through msm_amd_eval_reuse: evaluations queued back to back, one
+        synchronisation at the end; then the stage split of a few profiled steps."""
+        t = self.torch
+        k0 = self.nstep
+        for k in range(max(1, warmup)):                 # (the first call builds the lists)
+            self.eng.eval_reuse(self.r_sets[(k0 + k) % self.POSITION_SETS], self.q, skin, self.acc, want_energies=False)
+        t.cuda.synchronize()
+        _, rb0 = self.eng.reuse_stats()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            self.eng.eval_reuse(self.r_sets[(k0 + k) % self.POSITION_SETS], self.q, skin, self.acc, want_energies=False)
+        t.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        _, rb1 = self.eng.reuse_stats()
+        # the last step against msm_amd_eval of the same positions
+        rs = self.r_sets[(k0 + steps - 1) % self.POSITION_SETS]
+        en_r, acc_r = self.eng.eval_reuse(rs, self.q, skin)
+        acc_r = acc_r.clone()
+        en_e, acc_e = self.eng.eval(rs, self.q)
+        scale = float(np.abs(en_e[:6]).max())
+        out = {"evals_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "rebuilds_in_timed_steps": rb1 - rb0,
+               "vs_msm_amd_eval": {"energy_max_abs_diff_over_largest_component": float(np.abs(en_r - en_e).max() / scale),
+                                   "acc_rel_rms_diff": float(t.sqrt(((acc_r - acc_e) ** 2).sum() / (acc_e ** 2).sum()))},
+               "note": "msm_amd_eval_reuse: neighbour lists per group of 4 particles, built with cutoff a + skin and kept while no "
+                       "particle has moved more than skin / 2 (checked on the device by every call, which rebuilds them itself "
+                       "when needed); equal to msm_amd_eval to rounding, not bit for bit. A separate figure: `value` is "
+                       "msm_amd_eval, which assumes nothing about the previous call."}
+        self.eng.set_profiling(True)
+        acc = {}
+        for k in range(nprof):
+            self.eng.eval_reuse(self.r_sets[k % self.POSITION_SETS], self.q, skin, self.acc, want_energies=False)
+            t.cuda.synchronize()
+            tm = dict(self.eng.last_timings())
+            try:
+                tm["pair_kernel"] = self.eng.last_kernel_ms("pair_kernel")
+            except Exception:
+                pass
+            for kk, v in tm.items():
+                acc[kk] = acc.get(kk, 0.0) + v / nprof
+        self.eng.set_profiling(False)
+        out["kernel_ms"] = acc
+        out["pair_kernel_ms"] = acc.get("pair_kernel", 0.0)
+        return out
 
     def profile(self, n):
         # the engine brackets every stage, and the pair kernel by itself, with hipEventRecord on its own stream

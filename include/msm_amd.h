@@ -286,6 +286,21 @@ int msm_amd_eval_host(msm_amd_handle *h, const double *r, const double *q, doubl
  * Lets consecutive evaluations queue back to back (a time-stepping loop that reads energies every few steps). */
 int msm_amd_eval_enqueue(msm_amd_handle *h, const double *d_r, const double *d_q, double *d_acc, double *host_energies);
 
+/* msm_amd_eval for a sequence of evaluations whose positions change little from one to the next (a time-stepping
+ * loop).  No counterpart in the reference.  The handle keeps a frozen cluster order with, per group of 4 particles, the
+ * list of the particles that were within a + skin of one of them when the lists were last built; an evaluation moves
+ * the kept positions along with the caller's and sums over those lists (no box test, three lanes in four inside the
+ * cutoff).  Whether any particle has moved more than skin / 2 since then is checked ON THE DEVICE at the start of every
+ * call, and if so the same call rebuilds the lists before it uses them (the kernels of the rebuild are always queued and
+ * return at once otherwise), so the result never depends on the host seeing the flag.  The result equals
+ * msm_amd_eval's to rounding, not bit for bit: the sums run in the order of the last rebuild.  The first call
+ * allocates (about 1.2 kB per particle at skin = 0.1 a); later calls with a skin up to that one allocate nothing.
+ * Needs a periodic plan that owns every particle and plane (no slab rank, not the literal mode), 0 <= skin <= a, cell
+ * edges of at least 3 (a + skin).  energies as in msm_amd_eval (NULL: queued, no synchronisation). */
+int msm_amd_eval_reuse(msm_amd_handle *h, const double *d_r, const double *d_q, double *d_acc, double *energies, double skin);
+/* evaluations made through msm_amd_eval_reuse and list rebuilds among them (reads a device counter: synchronises) */
+int msm_amd_reuse_stats(msm_amd_handle *h, long *evaluations, long *rebuilds);
+
 /* ---- stage entry points (device pointers unless noted) ---- */
 /* bin particles; must precede pairs/anterpolate/interpolate of the same positions */
 int msm_amd_stage_bin(msm_amd_handle *h, const double *d_r, const double *d_q);

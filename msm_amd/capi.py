@@ -121,6 +121,8 @@ SIGNATURES = {
     "msm_amd_eval": (C.c_int, [_vp, _vp, _vp, _vp, _dp]),
     "msm_amd_eval_host": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
     "msm_amd_eval_enqueue": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "msm_amd_eval_reuse": (C.c_int, [_vp, _vp, _vp, _vp, _dp, C.c_double]),
+    "msm_amd_reuse_stats": (C.c_int, [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "msm_amd_stage_bin": (C.c_int, [_vp, _vp, _vp]),
     "msm_amd_stage_pairs": (C.c_int, [_vp, _vp]),
     "msm_amd_stage_anterpolate": (C.c_int, [_vp]),

@@ -567,7 +567,9 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) {
 // SLAB: the handle holds halo copies (only then can a neighbour be anything but fully owned; without them the fourth
 // section stays empty and its bookkeeping is left out of the kernel)
 template <bool SLAB>
-__global__ __launch_bounds__(256) void k_cl_list(ClusterGeom g, ClusterBuffers b, double a, double a2, int n_owned) {
+__global__ __launch_bounds__(256) void k_cl_list(ClusterGeom g, ClusterBuffers b, double a, double a2, int n_owned,
+                                                 const int *__restrict__ only_if) {
+    if (only_if && *only_if == 0) return; // (msm_amd_eval_reuse: lists are rebuilt only when the device-side check says so)
     const int lane = threadIdx.x & 63;
     const int icl = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int ncl = b.clstart[g.ncols];
@@ -1179,7 +1181,7 @@ __global__ __launch_bounds__(256, 4) void k_pair_clusters_split(ClusterGeom g, C
 template <int P>
 __device__ __forceinline__ void direct_one_cluster(const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double a,
                                                    double *__restrict__ acc, double *__restrict__ epart, int icl, int lane,
-                                                   bool half, bool onesided = false) {
+                                                   bool half, bool onesided = false, double a2_enum = 0.0) {
     const int ii = lane >> 3, jj = lane & 7;
     const LaneI I = load_lane_i(g, b, pp, icl, ii);
     if (!__ballot(I.owned)) {
@@ -1195,7 +1197,9 @@ __device__ __forceinline__ void direct_one_cluster(const ClusterGeom &g, const C
     // two clusters whose particles are all owned, half for the others
     double u1 = 0, uh = 0, unone = 0, fx = 0, fy = 0, fz = 0;
     const bool ifull = onesided && b.fbox[2 * (size_t)icl].w != 0.f;
-    cl_enumerate(g, b, a, pp.a2, ib, lane, [&](bool keep, int jcl, int code, bool jfull_lane) {
+    // (a, a2_enum: reach of the walk over the sort's bins - the cutoff, or more when the particles have moved since the
+    // sort; the pair arithmetic applies the cutoff itself)
+    cl_enumerate(g, b, a, a2_enum > 0.0 ? a2_enum : pp.a2, ib, lane, [&](bool keep, int jcl, int code, bool jfull_lane) {
         const int jfull_bits = (int)jfull_lane;
         unsigned long long m = __ballot(keep);
         while (m) {
@@ -1237,7 +1241,7 @@ __global__ __launch_bounds__(256) void k_pair_clusters_direct(ClusterGeom g, Clu
 template <int P>
 __global__ __launch_bounds__(256) void k_pair_clusters_overflow(ClusterGeom g, ClusterBuffers b, PairParams pp, double a,
                                                                 double *__restrict__ acc, double *__restrict__ epart,
-                                                                int half, int onesided) {
+                                                                int half, int onesided, double a2_enum) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const int ncl = b.clstart[g.ncols];
@@ -1246,8 +1250,298 @@ __global__ __launch_bounds__(256) void k_pair_clusters_overflow(ClusterGeom g, C
         while (m) {
             const int l = __ffsll((long long)m) - 1;
             m &= m - 1;
-            direct_one_cluster<P>(g, b, pp, a, acc, epart, base + l, lane, half != 0, onesided != 0);
+            direct_one_cluster<P>(g, b, pp, a, acc, epart, base + l, lane, half != 0, onesided != 0, a2_enum);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// neighbour structures kept over several evaluations (msm_amd_eval_reuse; every particle owned)
+// ---------------------------------------------------------------------------
+#define HL_PAD_CODE ((unsigned)CL_NOSHIFT << CL_CODE_SHIFT)
+
+// Every slot of the pair set follows its particle: new position = the caller's position wrapped into the cell exactly as
+// the sort wraps it, then the periodic image of that nearest the slot's position at the rebuild (so a caller that wraps
+// its coordinates moves nothing, a particle that crosses a face of the cell stays next to its neighbours, and the
+// coordinates are bit for bit those a fresh sort would hold, up to that whole image), charge as given now.  A particle that
+// has moved more than skin / 2 raises the flag that makes the kernels behind this one rebuild.  The 8 lanes of a cluster
+// also renew its bounding box (read by the list-free kernel only).
+__global__ __launch_bounds__(256) void k_reuse_follow(ClusterGeom g, ReuseBuffers rs, const double *__restrict__ r,
+                                                      const double *__restrict__ q, double half_skin2) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ncl = rs.counters[0];
+    if (s >= CL_G * ncl) return; // (whole clusters: 8 consecutive lanes leave together)
+    const int i = rs.order[s];
+    double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+    bool moved = false;
+    if (i != CL_DUMMY) {
+        const double4 ref = rs.ref[s];
+        const double refc[3] = {ref.x, ref.y, ref.z};
+        double nw[3], d2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const double t = (r[3 * (size_t)i + d] - g.origin[d]) * g.invA[d];
+            const double w = (t - floor(t)) * g.A[d];
+            nw[d] = w - g.A[d] * rint((w - refc[d]) * g.invA[d]);
+            const double dd = nw[d] - refc[d];
+            d2 = fma(dd, dd, d2);
+            l[d] = h[d] = nw[d];
+        }
+        moved = !(d2 <= half_skin2); // (a NaN position counts as moved)
+        rs.ps[s] = make_double4(nw[0], nw[1], nw[2], q[i]);
+    }
+    if (__ballot(moved) && (threadIdx.x & 63) == 0) atomicOr(rs.need, 1);
+#pragma unroll
+    for (int off = 1; off < CL_G; off <<= 1)
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            l[d] = fmin(l[d], __shfl_xor(l[d], off));
+            h[d] = fmax(h[d], __shfl_xor(h[d], off));
+        }
+    if ((s & (CL_G - 1)) == 0) {
+        const int k = s / CL_G;
+        rs.blo[k] = make_double4(l[0], l[1], l[2], 0.0);
+        rs.bhi[k] = make_double4(h[0], h[1], h[2], 0.0);
+        rs.fbox[2 * (size_t)k] = make_float4(__double2float_rd(l[0]), __double2float_rd(l[1]), __double2float_rd(l[2]), 1.f);
+        rs.fbox[2 * (size_t)k + 1] = make_float4(__double2float_ru(h[0]), __double2float_ru(h[1]), __double2float_ru(h[2]), 0.f);
+    }
+}
+
+// Rebuild, step 1 (only when the flag is up): the fresh sort becomes the pair set.
+__global__ __launch_bounds__(256) void k_reuse_adopt(ClusterGeom g, ClusterBuffers b, ReuseBuffers rs) {
+    if (*rs.need == 0) return;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+    const size_t nslots = (size_t)CL_G * g.max_clusters;
+    for (size_t s = t; s < nslots + CL_G; s += nt) { // (+ the cluster of inert slots behind the last one)
+        const double4 p = b.ps[s];
+        rs.ps[s] = p;
+        if (s < nslots) { rs.ref[s] = p; rs.order[s] = b.order[s]; }
+    }
+    for (size_t k = t; k < (size_t)g.max_clusters; k += nt) {
+        rs.blo[k] = b.blo[k]; rs.bhi[k] = b.bhi[k];
+        rs.fbox[2 * k] = b.fbox[2 * k]; rs.fbox[2 * k + 1] = b.fbox[2 * k + 1];
+    }
+    for (size_t k = t; k <= (size_t)g.nbins; k += nt) rs.start[k] = b.start[k];
+    for (size_t k = t; k <= (size_t)g.ncols; k += nt) { rs.clstart[k] = b.clstart[k]; rs.colncl[k] = b.colncl[k]; }
+    if (t == 0) { rs.counters[0] = b.clstart[g.ncols]; rs.counters[1] += 1; }
+}
+
+// Rebuild, step 3 (step 2 is k_cl_list with cutoff + skin): the half lists.  One wave per cluster walks its cluster
+// list 8 entries at a time, lane (e, s) = particle s of entry e, and tests that particle against the 8 particles of
+// the cluster themselves - squared distances in packed single precision against a cutoff widened by more than the
+// rounding of the converted coordinates, so that no pair double precision would keep is lost.  A particle within
+// cutoff + skin of one of the first four is appended to the lower half's list, of one of the last four to the upper
+// half's, in list order (ballot + lane rank), so the lists - and every sum made from them - do not depend on timing.
+__global__ __launch_bounds__(256) void k_reuse_halflists(ClusterGeom g, ClusterBuffers b, ReuseBuffers rs, float a2w) {
+    if (*rs.need == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int icl = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (icl >= b.clstart[g.ncols]) return;
+    const int nu = rs.n0[icl], ns = rs.n1[icl], nd = rs.n2[icl];
+    if (nu < 0) return; // its cluster list overflowed: the list-free kernel takes the cluster
+    v2f ix[4], iy[4], iz[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double4 p0 = b.ps[(size_t)CL_G * icl + 2 * k], p1 = b.ps[(size_t)CL_G * icl + 2 * k + 1];
+        ix[k] = (v2f){(float)p0.x, (float)p1.x}; // (padding slots lie far away on either side: they pass no test)
+        iy[k] = (v2f){(float)p0.y, (float)p1.y};
+        iz[k] = (v2f){(float)p0.z, (float)p1.z};
+    }
+    const int S = rs.list_stride, MID = S / 2;
+    const int *__restrict__ L = rs.list + (size_t)icl * S;
+    int *__restrict__ HA = rs.hl + ((size_t)icl * 2) * rs.hcap, *__restrict__ HB = HA + rs.hcap;
+    int tailA = 0, tailB = 0;
+    bool overflow = false;
+    const int sub = lane >> 3, sl = lane & 7;
+    auto walk = [&](const int *__restrict__ base, int dir, int n, bool shifted) {
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const unsigned mine = c0 + lane < n ? (unsigned)base[dir * (c0 + lane)] : 0u;
+            const int steps = (min(64, n - c0) + CL_G - 1) / CL_G;
+            for (int k = 0; k < steps; k++) {
+                const unsigned ent = __shfl(mine, CL_G * k + sub);
+                const bool live = c0 + CL_G * k + sub < n;
+                const unsigned slot = ((shifted ? ent & (unsigned)CL_JMASK : ent) << 3) + sl;
+                double4 p = b.ps[live ? slot : (unsigned)CL_G * g.max_clusters];
+                if (shifted) {
+                    double sx, sy, sz;
+                    shift_of_code(g, (int)(ent >> CL_CODE_SHIFT), sx, sy, sz);
+                    p.x += sx; p.y += sy; p.z += sz;
+                }
+                const float xf = (float)p.x, yf = (float)p.y, zf = (float)p.z;
+                const v2f X = (v2f){xf, xf}, Y = (v2f){yf, yf}, Z = (v2f){zf, zf};
+                v2f d[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const v2f dx = X - ix[m], dy = Y - iy[m], dz = Z - iz[m];
+                    d[m] = dx * dx + dy * dy + dz * dz;
+                }
+                const bool keepA = live && fminf(fminf(d[0].x, d[0].y), fminf(d[1].x, d[1].y)) < a2w;
+                const bool keepB = live && fminf(fminf(d[2].x, d[2].y), fminf(d[3].x, d[3].y)) < a2w;
+                const unsigned long long mA = __ballot(keepA), mB = __ballot(keepB);
+                const int cA = __popcll(mA), cB = __popcll(mB);
+                if (tailA + cA > rs.hcap || tailB + cB > rs.hcap) overflow = true;
+                if (!overflow) {
+                    // every entry carries a shift code (the zero shift for an unshifted neighbour)
+                    const int entry = (int)(slot | (shifted ? ent & ~(unsigned)CL_JMASK : HL_PAD_CODE));
+                    if (keepA) HA[tailA + lane_rank(mA)] = entry;
+                    if (keepB) HB[tailB + lane_rank(mB)] = entry;
+                }
+                tailA += cA;
+                tailB += cB;
+            }
+        }
+        // a section ends on a whole group of 16: the rest of its last group points at the cluster of inert slots
+        const int padA = (16 - (tailA & 15)) & 15, padB = (16 - (tailB & 15)) & 15;
+        if (tailA + padA > rs.hcap || tailB + padB > rs.hcap) overflow = true;
+        if (!overflow) {
+            const int inert = (int)((unsigned)CL_G * g.max_clusters | HL_PAD_CODE);
+            if (lane < padA) HA[tailA + lane] = inert;
+            if (lane < padB) HB[tailB + lane] = inert;
+        }
+        tailA += padA;
+        tailB += padB;
+    };
+    walk(L + 1, 1, nu - 1, false);
+    const int upA = tailA, upB = tailB;
+    walk(L + MID, 1, nd, false);
+    const int dnA = tailA - upA, dnB = tailB - upB;
+    walk(L + S - 1, -1, ns, true);
+    if (lane == 0) { // in groups of 16 entries
+        rs.hn[2 * (size_t)icl] = make_int4(upA >> 4, dnA >> 4, (tailA - upA - dnA) >> 4, 0);
+        rs.hn[2 * (size_t)icl + 1] = make_int4(upB >> 4, dnB >> 4, (tailB - upB - dnB) >> 4, 0);
+        if (overflow) rs.n0[icl] = -1; // a half list did not fit: the list-free kernel takes the cluster
+    }
+}
+
+// The pair sum over the half lists: one wave per cluster, lane = (hh, jj): particle hh of the lower half and particle
+// 4 + hh of the upper half against entry jj of a group of 16 of that half's list.  No test, no queue: every listed
+// particle was within cutoff + skin of its half at the rebuild, so about three lanes in four hold a pair inside the
+// cutoff (one in two when survivors of a box test are paired with all 8 particles of a cluster).  A step takes 64
+// list entries: every lane fetches one entry and its particle (one trip through the vector cache per particle, not one
+// per lane that uses it - with every lane gathering its own operand the kernel was bound by that cache, 1.0 ms), leaves
+// it in the wave's staging area in LDS as two 16-byte halves (16 consecutive entries of either array cover the 64 banks
+// once), and the four groups of 16 are read back as broadcasts; the particles of the next step are requested before
+// the current ones are used.  Energy bookkeeping as in k_pair_clusters_filtered with every particle owned: pairs with
+// clusters after this one whole, with clusters before it forces only, the cluster's own pairs and pairs through an
+// image half from either side.
+template <int P>
+__global__ __launch_bounds__(64, 4) void k_pair_halflists(ClusterGeom g, ReuseBuffers rs, PairParams pp, double *__restrict__ acc,
+                                                          double *__restrict__ epart) {
+    __shared__ double2 stage[2][64]; // (x, y) and (z, q) of the 64 particles of a step
+    const int lane = threadIdx.x, hh = lane >> 4, jj = lane & 15;
+    const int ncl = rs.counters[0];
+    const int icl = (int)blockIdx.x < ncl ? xcd_remap(blockIdx.x, ncl) : (int)blockIdx.x;
+    if (blockIdx.x == 0 && lane == 0) *rs.need = 0; // the rebuild of this evaluation, if there was one, is complete
+    if (icl >= ncl) {
+        if (lane == 0) epart[icl] = 0.0;
+        return;
+    }
+    if (rs.n0[icl] < 0) return; // left to the list-free kernel
+    ClusterBuffers view = {};
+    view.ps = rs.ps; view.order = rs.order;
+    const LaneI IA = load_lane_i(g, view, pp, icl, hh), IB = load_lane_i(g, view, pp, icl, CL_G / 2 + hh);
+    double u1A = 0, uhA = 0, fxA = 0, fyA = 0, fzA = 0, u1B = 0, uhB = 0, fxB = 0, fyB = 0, fzB = 0;
+    {   // the cluster's own pairs
+        const double4 own = rs.ps[(size_t)CL_G * icl + (jj & (CL_G - 1))];
+        cl_slot<P, true>(IA.x, IA.y, IA.z, own, pp, jj < CL_G && jj != hh, uhA, fxA, fyA, fzA);
+        cl_slot<P, true>(IB.x, IB.y, IB.z, own, pp, jj < CL_G && jj != CL_G / 2 + hh, uhB, fxB, fyB, fzB);
+    }
+    const unsigned pad = (unsigned)CL_G * g.max_clusters | HL_PAD_CODE; // the inert cluster: fails the cutoff
+    const char *__restrict__ psb = (const char *)rs.ps;
+    auto gather = [&](unsigned ent) { return *(const double4 *)(psb + ((size_t)(ent & (unsigned)CL_JMASK) << 5)); };
+    // One half's list as one stream of groups: gu groups of clusters after this one (energy whole), gd of clusters before
+    // it (forces only), gs through a periodic image (energy half).  List entries are requested two steps ahead and
+    // particles one step ahead, so neither of the two dependent loads of a step is waited for.
+    auto stream = [&](const int *__restrict__ list, int gu, int gd, int gs, const LaneI &I, double &u1, double &uh, double &fx,
+                      double &fy, double &fz) {
+        const int ng = gu + gd + gs, n = 16 * ng;
+        if (ng == 0) return;
+        unsigned ent0 = lane < n ? (unsigned)list[lane] : pad, ent1 = 64 + lane < n ? (unsigned)list[64 + lane] : pad;
+        double4 p = gather(ent0);
+        for (int e0 = 0; e0 < n; e0 += 64) {
+            if (e0 + 64 > 16 * (gu + gd)) { // (uniform) a step that reaches the last section: the image of the listed particle
+                double sx, sy, sz;          // next to this cluster (entries of the other sections carry the zero shift)
+                shift_of_code(g, (int)(ent0 >> CL_CODE_SHIFT), sx, sy, sz);
+                p.x += sx; p.y += sy; p.z += sz;
+            }
+            stage[0][lane] = make_double2(p.x, p.y);
+            stage[1][lane] = make_double2(p.z, p.w);
+            __builtin_amdgcn_wave_barrier();
+            ent0 = ent1;
+            p = gather(ent0);
+            ent1 = e0 + 128 + lane < n ? (unsigned)list[e0 + 128 + lane] : pad;
+            const int g0 = e0 >> 4, groups = min(4, ng - g0);
+            for (int k = 0; k < groups; k++) {
+                const double2 xy = stage[0][16 * k + jj], zq = stage[1][16 * k + jj];
+                const double4 pj = make_double4(xy.x, xy.y, zq.x, zq.y);
+                const int gk = g0 + k; // (uniform over the wave)
+                if (gk < gu) cl_slot<P, false>(I.x, I.y, I.z, pj, pp, true, u1, fx, fy, fz);
+                else if (gk < gu + gd) cl_slot_force<P>(I.x, I.y, I.z, pj, pp, fx, fy, fz);
+                else cl_slot<P, false>(I.x, I.y, I.z, pj, pp, true, uh, fx, fy, fz);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    const int *__restrict__ HA = rs.hl + ((size_t)icl * 2) * rs.hcap, *__restrict__ HB = HA + rs.hcap;
+    const int4 nA = rs.hn[2 * (size_t)icl], nB = rs.hn[2 * (size_t)icl + 1];
+    stream(HA, nA.x, nA.y, nA.z, IA, u1A, uhA, fxA, fyA, fzA);
+    stream(HB, nB.x, nB.y, nB.z, IB, u1B, uhB, fxB, fyB, fzB);
+    double e = 0.0;
+    auto finish = [&](const LaneI &I, double u, double fx, double fy, double fz) {
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            u += __shfl_xor(u, off);
+            fx += __shfl_xor(fx, off);
+            fy += __shfl_xor(fy, off);
+            fz += __shfl_xor(fz, off);
+        }
+        if (jj == 0 && I.orig != CL_DUMMY) {
+            const double w = pp.convention == MSM_AMD_ACC_FORCE ? -I.q : 1.0;
+            acc[3 * (size_t)I.orig] = w * fx;
+            acc[3 * (size_t)I.orig + 1] = w * fy;
+            acc[3 * (size_t)I.orig + 2] = w * fz;
+            e += 0.5 * I.q * u;
+        }
+    };
+    finish(IA, 2.0 * u1A + uhA, fxA, fyA, fzA);
+    finish(IB, 2.0 * u1B + uhB, fxB, fyB, fzB);
+    e = wave_sum(e);
+    if (lane == 0) epart[icl] = e;
+}
+
+void launch_reuse_pairs(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &main, const ReuseBuffers &rs, const PairParams &pp,
+                        const double *d_r, const double *d_q, double skin, double *acc, double *epart, hipEvent_t *ev) {
+    const double a = sqrt(pp.a2), amax = std::max(g.A[0], std::max(g.A[1], g.A[2]));
+    const int nslots = CL_G * g.max_clusters, nblk4 = (g.max_clusters + 3) / 4;
+    hipLaunchKernelGGL(k_reuse_follow, dim3((nslots + 255) / 256), dim3(256), 0, st, g, rs, d_r, d_q, 0.25 * skin * skin);
+    // rebuild (each of the three returns at once unless the flag is up)
+    hipLaunchKernelGGL(k_reuse_adopt, dim3(2048), dim3(256), 0, st, g, main, rs);
+    {
+        ClusterGeom gw = g; // cluster lists with cutoff + skin, in the pair set's own list buffer
+        const double aw = a + skin;
+        gw.list_stride = rs.list_stride;
+        { const double w = aw + 4e-6 * amax; gw.a2_wide = (float)(w * w * (1.0 + 1e-6)); }
+        ClusterBuffers bw = main;
+        bw.list = rs.list; bw.n0 = rs.n0; bw.n1 = rs.n1; bw.n2 = rs.n2;
+        hipLaunchKernelGGL(k_cl_list<false>, dim3(nblk4), dim3(256), 0, st, gw, bw, aw, aw * aw, pp.n_owned, (const int *)rs.need);
+        // cutoff of the single-precision test: coordinates up to 2 A (a periodic image) carry 2^-24 relative rounding each
+        const double eps = 2e-6 * amax / aw + 4e-6;
+        const float a2w = (float)(aw * aw * (1.0 + eps)) * 1.000001f;
+        hipLaunchKernelGGL(k_reuse_halflists, dim3(nblk4), dim3(256), 0, st, g, main, rs, a2w);
+    }
+    if (ev) hipEventRecord(ev[0], st);
+    if (pp.p == 4) hipLaunchKernelGGL((k_pair_halflists<4>), dim3(g.max_clusters), dim3(64), 0, st, g, rs, pp, acc, epart);
+    else hipLaunchKernelGGL((k_pair_halflists<6>), dim3(g.max_clusters), dim3(64), 0, st, g, rs, pp, acc, epart);
+    if (ev) hipEventRecord(ev[1], st);
+    {   // clusters whose lists overflowed: list-free, over the frozen bins with a reach that covers the motion since the sort
+        ClusterGeom go = g;
+        const double ar = a + 0.5 * skin + 1e-9 * amax;
+        { const double w = ar + 4e-6 * amax; go.a2_wide = (float)(w * w * (1.0 + 1e-6)); }
+        ClusterBuffers bo = {};
+        bo.start = rs.start; bo.clstart = rs.clstart; bo.colncl = rs.colncl; bo.order = rs.order; bo.ps = rs.ps;
+        bo.blo = rs.blo; bo.bhi = rs.bhi; bo.fbox = rs.fbox; bo.n0 = rs.n0;
+        if (pp.p == 4) hipLaunchKernelGGL((k_pair_clusters_overflow<4>), dim3(std::min(nblk4, 2048)), dim3(256), 0, st, go, bo, pp, ar, acc, epart, 1, 0, ar * ar);
+        else hipLaunchKernelGGL((k_pair_clusters_overflow<6>), dim3(std::min(nblk4, 2048)), dim3(256), 0, st, go, bo, pp, ar, acc, epart, 1, 0, ar * ar);
     }
 }
 
@@ -1269,11 +1563,11 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
     // halo copies) need its length written: only those one-sided kernels go with the list build that leaves it out
     const bool h = half && variant != 2; // variant 2: every pair counted half from both sides (A/B)
     if (list_wpb == 1) {
-        if (h) hipLaunchKernelGGL(k_cl_list<false>, dim3(g.max_clusters), dim3(64), 0, st, g, b, a, pp.a2, pp.n_owned);
-        else hipLaunchKernelGGL(k_cl_list<true>, dim3(g.max_clusters), dim3(64), 0, st, g, b, a, pp.a2, pp.n_owned);
+        if (h) hipLaunchKernelGGL(k_cl_list<false>, dim3(g.max_clusters), dim3(64), 0, st, g, b, a, pp.a2, pp.n_owned, (const int *)nullptr);
+        else hipLaunchKernelGGL(k_cl_list<true>, dim3(g.max_clusters), dim3(64), 0, st, g, b, a, pp.a2, pp.n_owned, (const int *)nullptr);
     } else {
-        if (h) hipLaunchKernelGGL(k_cl_list<false>, dim3(nblk), dim3(256), 0, st, g, b, a, pp.a2, pp.n_owned);
-        else hipLaunchKernelGGL(k_cl_list<true>, dim3(nblk), dim3(256), 0, st, g, b, a, pp.a2, pp.n_owned);
+        if (h) hipLaunchKernelGGL(k_cl_list<false>, dim3(nblk), dim3(256), 0, st, g, b, a, pp.a2, pp.n_owned, (const int *)nullptr);
+        else hipLaunchKernelGGL(k_cl_list<true>, dim3(nblk), dim3(256), 0, st, g, b, a, pp.a2, pp.n_owned, (const int *)nullptr);
     }
     if (after_lists) hipEventRecord(after_lists, st); // lets another stream start beside the pair kernel, not beside the list build
 #define LAUNCH_PC(P, HALF, U)                                                                                  \
@@ -1317,9 +1611,9 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
         else LAUNCH_PC(6, false, 4);
     }
     if (pp.p == 4) {
-        hipLaunchKernelGGL((k_pair_clusters_overflow<4>), dim3(std::min(nblk, 2048)), dim3(256), 0, st, g, b, pp, a, acc, epart, h ? 1 : 0, onesided);
+        hipLaunchKernelGGL((k_pair_clusters_overflow<4>), dim3(std::min(nblk, 2048)), dim3(256), 0, st, g, b, pp, a, acc, epart, h ? 1 : 0, onesided, 0.0);
     } else {
-        hipLaunchKernelGGL((k_pair_clusters_overflow<6>), dim3(std::min(nblk, 2048)), dim3(256), 0, st, g, b, pp, a, acc, epart, h ? 1 : 0, onesided);
+        hipLaunchKernelGGL((k_pair_clusters_overflow<6>), dim3(std::min(nblk, 2048)), dim3(256), 0, st, g, b, pp, a, acc, epart, h ? 1 : 0, onesided, 0.0);
     }
 #undef LAUNCH_PC
 #undef LAUNCH_PF

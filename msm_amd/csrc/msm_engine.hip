@@ -90,6 +90,12 @@ struct msm_amd_handle {
     double4 *acc_slots = nullptr;
     int opt_acc_slots = 1;      // 0: the pair kernels scatter into the caller's array themselves (A/B)
     bool fused_acc = false;     // set for the duration of a whole evaluation that qualifies
+    // msm_amd_eval_reuse: the pair set and its lists (allocated by the first call, sized for its skin)
+    ReuseBuffers rs = {};
+    bool rs_made = false;
+    double rs_skin = -1.0;      // skin the lists in the buffers were built with (a change makes the next call rebuild)
+    double rs_skin_cap = 0.0;   // largest skin the buffers are sized for
+    long rs_evals = 0;
     // LDS-tiled anterpolation
     TileGeom tiles = {};
     double *tile_scratch = nullptr;
@@ -500,6 +506,17 @@ extern "C" int msm_amd_create_literal(const msm_amd_plan_desc *plan, int device,
     return create_impl(plan, true, device, stream, out);
 }
 
+static void free_reuse(msm_amd_handle *h) {
+    ReuseBuffers &rs = h->rs;
+    hipFree(rs.ps); hipFree(rs.ref); hipFree(rs.order); hipFree(rs.blo); hipFree(rs.bhi); hipFree(rs.fbox);
+    hipFree(rs.start); hipFree(rs.clstart); hipFree(rs.colncl); hipFree(rs.list); hipFree(rs.n0); hipFree(rs.n1); hipFree(rs.n2);
+    hipFree(rs.hl); hipFree(rs.hn); hipFree(rs.need); hipFree(rs.counters);
+    rs = ReuseBuffers();
+    h->rs_made = false;
+    h->rs_skin = -1.0;
+    h->rs_skin_cap = 0.0;
+}
+
 extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     if (!h) return;
     hipSetDevice(h->device);
@@ -525,6 +542,7 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     hipFree(h->s_r); hipFree(h->s_q); hipFree(h->s_acc); hipFree(h->s_acc2); hipFree(h->conv_part);
     hipFree(h->lit_part_d[0]); hipFree(h->lit_part_d[1]); hipFree(h->lit_part_e);
     hipFree(h->acc_slots);
+    free_reuse(h);
     if (h->stream_b) {
         hipStreamSynchronize(h->stream_b);
         hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_pairs); hipEventDestroy(h->ev_join);
@@ -1291,6 +1309,127 @@ extern "C" int msm_amd_eval(msm_amd_handle *h, const double *d_r, const double *
         h->last_ms[T_TOTAL] = ms;
         h->pair_kernel_ms = -1.0;
         if (h->pk_recorded && hipEventElapsedTime(&ms, h->ev_pk[0], h->ev_pk[1]) == hipSuccess) h->pair_kernel_ms = ms;
+    }
+    return MSM_AMD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// evaluations that keep their neighbour structures (no counterpart in the reference)
+// ---------------------------------------------------------------------------
+static int ensure_reuse(msm_amd_handle *h, double skin) {
+    if (h->rs_made && skin <= h->rs_skin_cap) return MSM_AMD_OK;
+    if (h->rs_made) { // a larger skin than the buffers hold: start over (synchronises)
+        HIPCHK(hipStreamSynchronize(h->stream));
+        free_reuse(h);
+    }
+    const msm_amd_plan_desc &d = h->hp.d;
+    const ClusterGeom &cg = h->clg;
+    ReuseBuffers &rs = h->rs;
+    const size_t nslots = (size_t)cg.max_clusters * CL_G, ncl = (size_t)cg.max_clusters;
+    const double vol = d.A[0] * d.A[1] * d.A[2], rho = std::max(h->capacity, 1) / vol, aw = d.a + skin;
+    {   // cluster lists for cutoff + skin: the sizing rule of msm_amd_create with the wider cutoff
+        const double e = std::cbrt(8.0 / rho);
+        const double vexp = e * e * e + 6.0 * e * e * aw + 3.0 * M_PI * aw * aw * e + 4.0 / 3.0 * M_PI * aw * aw * aw;
+        const double est = 1.5 * vexp * rho / 8.0;
+        long half = std::max(192L, ((long)(1.3 * est) + 31) / 32 * 32);
+        const long cap = (1L << 32) / std::max(1, cg.max_clusters) / 2 / 32 * 32;
+        rs.list_stride = (int)(2 * std::max(192L, std::min(half, cap)));
+    }
+    // half lists: particles within cutoff + skin of one of 4 neighbouring particles, with room for fluctuations
+    // (measured at the benchmark's density: 2.1 spheres' worth; sections end on whole groups of 16)
+    rs.hcap = (int)(((long)(1.4 * 2.1 * 4.0 / 3.0 * M_PI * aw * aw * aw * rho) + 96 + 31) / 32 * 32);
+    int rc = MSM_AMD_OK;
+#define RA(ptr, n) do { if (!rc) rc = dalloc(&(ptr), (size_t)(n)); } while (0)
+    RA(rs.ps, nslots + CL_G); RA(rs.ref, nslots); RA(rs.order, nslots);
+    RA(rs.blo, ncl); RA(rs.bhi, ncl); RA(rs.fbox, 2 * ncl);
+    RA(rs.start, (size_t)cg.nbins + 1); RA(rs.clstart, (size_t)cg.ncols + 1); RA(rs.colncl, (size_t)cg.ncols + 1);
+    RA(rs.list, ncl * rs.list_stride); RA(rs.n0, ncl); RA(rs.n1, ncl); RA(rs.n2, ncl);
+    RA(rs.hl, ncl * 2 * (size_t)rs.hcap); RA(rs.hn, 2 * ncl);
+    RA(rs.need, 1); RA(rs.counters, 2);
+#undef RA
+    if (rc) { free_reuse(h); return rc; }
+    h->rs_made = true;
+    h->rs_skin_cap = skin;
+    h->rs_skin = -1.0;
+    HIPCHK(hipMemsetAsync(rs.counters, 0, 2 * sizeof(int), h->stream));
+    return MSM_AMD_OK;
+}
+
+extern "C" int msm_amd_eval_reuse(msm_amd_handle *h, const double *d_r, const double *d_q, double *d_acc, double *energies,
+                                  double skin) {
+    if (!h || !d_r || !d_q || !d_acc) { set_error("msm_amd_eval_reuse: null argument"); return MSM_AMD_EINVAL; }
+    const msm_amd_plan_desc &d = h->hp.d;
+    if (!(skin >= 0.0) || !(skin <= d.a)) { set_error("msm_amd_eval_reuse: the skin must lie in [0, a]"); return MSM_AMD_EINVAL; }
+    if (h->small_box || h->hp.literal || h->pp.convention == MSM_AMD_ACC_LITERAL || h->n_owned != h->N || d.nzplanes != d.M[2] ||
+        d.open_boundary || h->clg.max_clusters >= (1 << 24)) {
+        set_error("msm_amd_eval_reuse: needs a periodic plan of at least 3 cutoffs per cell edge that owns every particle and "
+                  "every plane (not the literal mode, not a slab rank), and fewer than 2^24 clusters");
+        return MSM_AMD_EINVAL;
+    }
+    for (int k = 0; k < 3; k++)
+        if (d.A[k] < 3.0 * (d.a + skin)) { set_error("msm_amd_eval_reuse: the cell must be at least 3 (a + skin) wide"); return MSM_AMD_EINVAL; }
+    HIPCHK(hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure_reuse(h, skin))) return rc;
+    if (skin != h->rs_skin) { // first call, or a new skin: the lists are built (again) by this evaluation
+        HIPCHK(hipMemsetAsync(h->rs.need, 1, sizeof(int), h->stream)); // (any non-zero value raises the flag)
+        h->rs_skin = skin;
+    }
+    h->pk_recorded = false;
+    mark(h, T_BIN);
+    // the fresh sort: what the tile kernels of the grid transfer walk, and what a rebuild adopts
+    const int variant = h->opt_pair_variant;
+    h->opt_pair_variant = 8;
+    rc = msm_amd_stage_bin(h, d_r, d_q);
+    h->opt_pair_variant = variant;
+    if (rc) return rc;
+    mark(h, T_PAIR);
+    launch_reuse_pairs(h->stream, h->clg, h->clb, h->rs, h->pp, d_r, d_q, skin, d_acc, h->epart, h->profiling ? h->ev_pk : nullptr);
+    h->pk_recorded = h->profiling;
+    h->nepart = h->clg.max_clusters;
+    HIPCHK(hipGetLastError());
+    mark(h, T_ANT);
+    if ((rc = msm_amd_stage_anterpolate(h))) return rc;
+    if ((rc = msm_amd_stage_grid(h))) return rc; // marks T_RES..T_PRO
+    mark(h, T_INT);
+    if ((rc = msm_amd_stage_interpolate(h, d_acc))) return rc;
+    mark(h, T_RED);
+    if ((rc = queue_energies(h))) return rc;
+    mark(h, T_TOTAL);
+    h->rs_evals++;
+    if (energies) {
+        HIPCHK(hipMemcpyAsync(h->h_energies, h->d_energies, MSM_AMD_U_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        memcpy(energies, h->h_energies, MSM_AMD_U_COUNT * sizeof(double));
+    }
+    if (h->profiling) {
+        HIPCHK(hipEventSynchronize(h->ev[T_TOTAL]));
+        for (int i = 0; i < T_TOTAL; i++) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]);
+            h->last_ms[i] = ms;
+        }
+        float ms = 0;
+        hipEventElapsedTime(&ms, h->ev[T_BIN], h->ev[T_TOTAL]);
+        h->last_ms[T_TOTAL] = ms;
+        h->pair_kernel_ms = -1.0;
+        if (hipEventElapsedTime(&ms, h->ev_pk[0], h->ev_pk[1]) == hipSuccess) h->pair_kernel_ms = ms;
+    }
+    return MSM_AMD_OK;
+}
+
+extern "C" int msm_amd_reuse_stats(msm_amd_handle *h, long *evaluations, long *rebuilds) {
+    if (!h) return MSM_AMD_EINVAL;
+    if (evaluations) *evaluations = h->rs_evals;
+    if (rebuilds) {
+        *rebuilds = 0;
+        if (h->rs_made) {
+            int c[2] = {0, 0};
+            HIPCHK(hipSetDevice(h->device));
+            HIPCHK(hipMemcpyAsync(c, h->rs.counters, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            *rebuilds = c[1];
+        }
     }
     return MSM_AMD_OK;
 }

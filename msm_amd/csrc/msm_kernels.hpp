@@ -127,6 +127,31 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
                           double *epart, int variant, int n_total, hipEvent_t *ev, int max_wgs = 0, hipEvent_t after_lists = nullptr,
                           int lds_pad = 0); // lds_pad: unused LDS bytes per workgroup of the list-walking kernel (caps the waves per SIMD)
 
+// ---- neighbour structures kept over several evaluations (msm_amd_eval_reuse) ----
+// The "pair set": the cluster order of the last rebuild, frozen (slots, original indices, fine-bin prefix sums), with
+// positions that follow the particles; per half cluster (4 particles) the slots of the particles that were within
+// cutoff + skin of one of its 4 at the rebuild, in three sections (clusters after it / before it / through a periodic
+// image).  While no particle has moved more than skin / 2 since the rebuild, every pair inside the cutoff is listed.
+struct ReuseBuffers {
+    double4 *ps, *ref;          // current / rebuild-time position and charge per slot (ps has one inert cluster behind the last slot)
+    int *order;                 // original index per slot, CL_DUMMY for padding
+    double4 *blo, *bhi;         // cluster bounding boxes of the current positions (for the list-free kernel)
+    float4 *fbox;
+    int *start, *clstart, *colncl; // frozen copies of the sort's prefix sums
+    int *list, *n0, *n1, *n2;   // cluster lists built with cutoff + skin (n0 < 0: this cluster goes to the list-free kernel)
+    int list_stride;
+    int *hl;                    // half lists: [cluster][half][hcap] entries (slot | shift code << 27), each section padded to 16
+    int4 *hn;                   // per (cluster, half): groups of 16 entries after / before / through an image
+    int hcap;
+    int *need;                  // device flag: 1 = the next evaluation rebuilds (set by the displacement check, cleared by the pair kernel)
+    int *counters;              // [0] clusters at the rebuild, [1] rebuilds so far
+};
+// one evaluation's short-range part from the pair set: displacement check and position update, (conditionally, decided
+// on the device) adoption of the fresh sort in `main`, cluster lists and half lists with cutoff + skin, then the pair
+// kernel over the half lists and the list-free kernel for clusters whose lists overflowed
+void launch_reuse_pairs(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &main, const ReuseBuffers &rs, const PairParams &pp,
+                        const double *d_r, const double *d_q, double skin, double *acc, double *epart, hipEvent_t *ev);
+
 // ---- short range ----
 void launch_pair_cells(hipStream_t st, const double4 *ps, const int *cstart, const int *order, int ncell,
                        const PairParams &pp, double *acc, double *epart, int variant);

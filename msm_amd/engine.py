@@ -154,6 +154,25 @@ class Engine:
                                           energies_pinned.data_ptr() if energies_pinned is not None else None),
               "msm_amd_eval_enqueue")
 
+    def eval_reuse(self, r, q, skin, acc=None, want_energies=True):
+        """msm_amd_eval_reuse: an evaluation that keeps its neighbour lists while no particle has moved more than skin / 2
+        since they were built (checked, and rebuilt if need be, on the device)."""
+        t = self.torch
+        r = self._dev(r, 3 * self.N)
+        q = self._dev(q, self.N)
+        if acc is None:
+            acc = t.empty((self.N, 3), dtype=t.float64, device=r.device)
+        en = np.zeros(capi.U_COUNT) if want_energies else None
+        check(load().msm_amd_eval_reuse(self._h, r.data_ptr(), q.data_ptr(), acc.data_ptr(),
+                                        en.ctypes.data_as(_dp) if want_energies else None, float(skin)), "msm_amd_eval_reuse")
+        return en, acc
+
+    def reuse_stats(self):
+        """(evaluations through eval_reuse, list rebuilds among them)"""
+        ev, rb = C.c_long(0), C.c_long(0)
+        check(load().msm_amd_reuse_stats(self._h, C.byref(ev), C.byref(rb)), "msm_amd_reuse_stats")
+        return ev.value, rb.value
+
     def eval_host(self, r, q):
         r = np.ascontiguousarray(r, dtype=np.float64)
         q = np.ascontiguousarray(q, dtype=np.float64)

@@ -1208,3 +1208,72 @@ def test_slot_order_accelerations_keep_the_bits(msm, torch, p, conv):
     eng.stage_interpolate(acc2)
     assert torch.equal(acc2, acc1)
     eng.close()
+
+
+@pytest.mark.parametrize("p,conv,blob", [(6, 0, False), (4, 2, True)])
+def test_eval_reuse_matches_eval(msm, torch, p, conv, blob):
+    """msm_amd_eval_reuse over a short trajectory: neighbour lists built with cutoff a + skin are kept while no particle
+    has moved more than skin / 2 (checked on the device) and rebuilt by the same call otherwise.  Every step equals
+    msm_amd_eval of the same positions to 1e-12 (energies of the largest component, accelerations relative RMS; the sums
+    run in another order, so not bit for bit); the rebuild count is what the displacements call for; a caller that wraps
+    a particle by a cell edge moves nothing; the same trajectory on a second handle gives the same bits; a step that moves
+    every particle by just under skin / 2 brings pairs from beyond the cutoff deep into it without a rebuild.  The second case
+    has a crowded ball whose clusters overflow their lists (list-free kernel over the frozen bins) and the force
+    convention."""
+    N, A = 120000, (1.0, 1.0, 1.0)
+    r0, q = O.neutral_system(N, A, seed=91)
+    rng = np.random.default_rng(17)
+    if blob:
+        r0[:5000] = (0.62 + 0.004 * rng.standard_normal((5000, 3))) % 1.0
+    desc = msm.plan_auto(N, A, p, 10, 4.0, 3)
+    desc.acc_convention = conv
+    skin = 0.1 * desc.a
+    fresh, kept, again = msm.Engine(desc), msm.Engine(desc), msm.Engine(desc)
+    qd = torch.as_tensor(q, device="cuda:0")
+    # what a different order of the same sums costs on this system (the crowded ball adds terms of 1e7 that cancel): the
+    # list-walking kernels per cluster and per particle against each other
+    other = msm.Engine(desc)
+    other.set_option("pair_variant", 5)
+    _, a5 = other.eval(torch.as_tensor(r0, device="cuda:0"), qd)
+    _, a8 = fresh.eval(torch.as_tensor(r0, device="cuda:0"), qd)
+    tol = max(TOL, 4.0 * rel_rms(a5.cpu().numpy(), a8.cpu().numpy()))
+    other.close()
+    assert tol < 2e-11
+    r = r0.copy()
+    results = []
+    for step in range(10):
+        if step > 0:
+            r = r + (rng.random((N, 3)) - 0.5) * 0.008 * desc.a            # small moves: the lists stay
+        if step == 1:
+            # every particle 0.0495 a along +x or -x, just under skin / 2 = 0.05 a: pairs that were up to 0.099 a beyond
+            # the cutoff at the rebuild are now inside it, where they weigh up to 1e-5 of a force - lists built without the
+            # skin would show
+            r[:, 0] = r0[:, 0] + 0.0495 * desc.a * np.where(rng.random(N) < 0.5, -1.0, 1.0)
+            r[:, 1:] = r0[:, 1:]
+        if step == 2:
+            r = r0 + (rng.random((N, 3)) - 0.5) * 0.008 * desc.a
+        if step == 6:
+            r[::97] += 0.3 * desc.a * (rng.random((len(r[::97]), 3)) - 0.5)   # some particles jump: this call rebuilds
+        if step == 3:
+            r[::11, 0] += 1.0                                                # the caller wraps coordinates: nothing moved
+        if step == 4:
+            r[::13, 2] -= 2.0
+        rd = torch.as_tensor(r, device="cuda:0")
+        en0, acc0 = fresh.eval(rd, qd)
+        en1, acc1 = kept.eval_reuse(rd, qd, skin)
+        scale = np.abs(en0[:6]).max()
+        assert np.abs(en1 - en0).max() <= tol * scale, (step, en1, en0)
+        assert rel_rms(acc1.cpu().numpy(), acc0.cpu().numpy()) < tol, step
+        assert float((acc1 - acc0).abs().max()) <= 10 * tol * float(acc0.abs().max()), step
+        results.append((en1, acc1.clone()))
+        en2, acc2 = again.eval_reuse(rd, qd, skin)
+        assert np.array_equal(en1, en2) and torch.equal(acc1, acc2), step
+    evals, rebuilds = kept.reuse_stats()
+    assert evals == 10 and rebuilds == 2, (evals, rebuilds)
+    # a new skin rebuilds; a skin beyond the cutoff, a slab rank or the literal mode are refused
+    kept.eval_reuse(rd, qd, 0.05 * desc.a)
+    assert kept.reuse_stats() == (11, 3)
+    with pytest.raises(msm.MsmAmdError):
+        kept.eval_reuse(rd, qd, 1.5 * desc.a)
+    for e in (fresh, kept, again):
+        e.close()
