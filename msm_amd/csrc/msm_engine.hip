@@ -571,6 +571,7 @@ extern "C" int msm_amd_set_counts(msm_amd_handle *h, int n_total, int n_owned) {
     h->pp.n_owned = n_owned;
     h->sp.n_owned = n_owned;
     h->clg.n_owned = n_owned >= n_total ? CL_ALL_OWNED : n_owned;
+    h->rs_skin = -1.0; // (lists kept by msm_amd_eval_reuse describe another set of particles: its next call rebuilds)
     return MSM_AMD_OK;
 }
 
