@@ -1277,3 +1277,29 @@ def test_eval_reuse_matches_eval(msm, torch, p, conv, blob):
         kept.eval_reuse(rd, qd, 1.5 * desc.a)
     for e in (fresh, kept, again):
         e.close()
+
+
+@pytest.mark.parametrize("N,A,p,L", [(5000, (1.0, 1.1, 0.9), 4, 2), (30000, (1.3, 1.0, 1.1), 6, 2)])
+def test_eval_reuse_small_and_skewed_plans(msm, torch, N, A, p, L):
+    """msm_amd_eval_reuse on plans that take the other code paths: a grid too small for the tiled grid transfer (the
+    columns of the sort are then not aligned with grid cells and a second, grid-cell sort feeds the spline kernels) and a
+    cell with three different edges; a random walk of the particles with one jump, against msm_amd_eval to 1e-12."""
+    r, q = O.neutral_system(N, A, seed=5)
+    rng = np.random.default_rng(23)
+    desc = msm.plan_auto(N, A, p, 10, 4.0, L)
+    skin = 0.08 * desc.a
+    fresh, kept = msm.Engine(desc), msm.Engine(desc)
+    qd = torch.as_tensor(q, device="cuda:0")
+    for step in range(6):
+        if step:
+            r = r + (rng.random((N, 3)) - 0.5) * 0.01 * desc.a
+        if step == 3:
+            r[::7] += 0.4 * desc.a
+        rd = torch.as_tensor(r, device="cuda:0")
+        en0, acc0 = fresh.eval(rd, qd)
+        en1, acc1 = kept.eval_reuse(rd, qd, skin)
+        assert np.abs(en1 - en0).max() <= TOL * np.abs(en0[:6]).max(), step
+        assert rel_rms(acc1.cpu().numpy(), acc0.cpu().numpy()) < TOL, step
+    assert kept.reuse_stats() == (6, 2)
+    fresh.close()
+    kept.close()
