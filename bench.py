@@ -281,6 +281,10 @@ def main():
             out["accuracy"] = accuracy
         print(json.dumps(out))
     if dist is not None:
+        # the library's communicator goes before the process group it was negotiated over
+        barrier()
+        if getattr(stepper, "coll", None) is not None:
+            stepper.coll.close()
         dist.destroy_process_group()
 
 
