@@ -234,7 +234,7 @@ __global__ __launch_bounds__(1024) void k_cs_colscan(const int *__restrict__ col
         int vp = 0, vc = 0;
         if (col < g.ncols) {
             vp = coltotal[col];
-            vc = (vp + CL_G - 1) / CL_G;
+            vc = (vp + CL_G - 1) / CL_G + g.nface; // (room for the padding at the faces of a slab)
             colncl[col] = vc;
         }
         int ip = vp, ic = vc;
@@ -330,13 +330,29 @@ __global__ __launch_bounds__(256) void k_cs_colsort(ClusterGeom g, ClusterBuffer
         for (int w = 0; w < wave; w++) before += wtot[w];
         if (z < g.nzf) {
             zs[z] = before + incl - v;
-            b.start[(size_t)col * g.nzf + z] = p0 + before + incl - v;
+            if (!g.nface) b.start[(size_t)col * g.nzf + z] = p0 + before + incl - v;
         }
         __syncthreads();
         if (threadIdx.x == 255) carry = before + incl;
         __syncthreads();
     }
-    if (col == g.ncols - 1 && threadIdx.x == 0) b.start[(size_t)g.ncols * g.nzf] = p0 + n;
+    if (!g.nface && col == g.ncols - 1 && threadIdx.x == 0) b.start[(size_t)g.ncols * g.nzf] = p0 + n;
+    // A slab rank: a new cluster starts where ownership changes along the column.  pad0 / pad1 inert slots complete the
+    // cluster before the first / second face; a particle of rank r in fine bin z then sits in slot r + fpad(z) of the
+    // column, and start[] holds slots instead of particle counts (which is all its readers ask of it: they take
+    // differences inside a column and divide by the cluster size).
+    int pad0 = 0, pad1 = 0, f0 = g.nzf, f1 = g.nzf, r0 = n, r1 = n; // r0, r1: particles below the faces
+    if (g.nface) {
+        f0 = g.face[0]; f1 = g.face[1];
+        r0 = f0 < g.nzf ? zs[f0] : n;
+        r1 = f1 < g.nzf ? zs[f1] : n;
+        pad0 = f0 < g.nzf ? (CL_G - r0 % CL_G) % CL_G : 0;
+        pad1 = f1 < g.nzf ? (CL_G - (r1 - r0) % CL_G) % CL_G : 0;
+        for (int z = threadIdx.x; z < g.nzf; z += 256)
+            b.start[(size_t)col * g.nzf + z] = CL_G * c0 + zs[z] + (z >= f0 ? pad0 : 0) + (z >= f1 ? pad1 : 0);
+        if (col == g.ncols - 1 && threadIdx.x == 0) b.start[(size_t)g.ncols * g.nzf] = CL_G * (c0 + ncl);
+    }
+    auto fpad = [&](int z) { return (z >= f0 ? pad0 : 0) + (z >= f1 ? pad1 : 0); };
     // rank of a particle inside the column: particles in lower fine bins + particles of its bin with a lower original index
     if (n <= CS_CAP) {
         for (int z = threadIdx.x; z < g.nzf; z += 256) zh[z] = 0;
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(256) void k_cs_colsort(ClusterGeom g, ClusterBuffer
             const int m0 = zs[z], m1 = m0 + zh[z];
             int rank = m0;
             for (int m = m0; m < m1; m++) rank += u.member[m] < idx;
-            const size_t dst = (size_t)CL_G * c0 + rank;
+            const size_t dst = (size_t)CL_G * c0 + rank + fpad(z);
             b.ps[dst] = b.bps[p0 + e];
             b.order[dst] = idx;
         }
@@ -373,14 +389,19 @@ __global__ __launch_bounds__(256) void k_cs_colsort(ClusterGeom g, ClusterBuffer
                     for (int j = 0; j < m; j++) rank += u.keys[j] < key;
             }
             if (e < n) {
-                const size_t dst = (size_t)CL_G * c0 + rank;
+                const size_t dst = (size_t)CL_G * c0 + rank + fpad((int)(key >> 32));
                 b.ps[dst] = b.bps[p0 + e];
                 b.order[dst] = (int)(unsigned)key;
             }
         }
     }
-    // padding of the column's last cluster
-    for (int m = n + threadIdx.x; m < CL_G * ncl; m += 256) {
+    // padding: behind the column's last particle up to the end of its clusters, and in front of the faces of a slab
+    for (int m = n + pad0 + pad1 + threadIdx.x; m < CL_G * ncl; m += 256) {
+        b.ps[(size_t)CL_G * c0 + m] = make_double4(g.far, g.far, g.far, 0.0);
+        b.order[(size_t)CL_G * c0 + m] = CL_DUMMY;
+    }
+    if ((int)threadIdx.x < pad0 + pad1) {
+        const int m = (int)threadIdx.x < pad0 ? r0 + (int)threadIdx.x : r1 + pad0 + ((int)threadIdx.x - pad0);
         b.ps[(size_t)CL_G * c0 + m] = make_double4(g.far, g.far, g.far, 0.0);
         b.order[(size_t)CL_G * c0 + m] = CL_DUMMY;
     }
@@ -389,11 +410,12 @@ __global__ __launch_bounds__(256) void k_cs_colsort(ClusterGeom g, ClusterBuffer
     __syncthreads();
     // bounding boxes of the column's clusters (the slots were written by this workgroup: visible after the barriers)
     for (int k = threadIdx.x; k < ncl; k += 256) {
-        const int nin = min(CL_G, n - CL_G * k);
+        const int nin = g.nface ? CL_G : min(CL_G, n - CL_G * k); // (with padding inside the column: whoever is no padding)
         const double4 *p = b.ps + (size_t)CL_G * (c0 + k);
         double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
         bool all_owned = true;
         for (int m = 0; m < nin; m++) {
+            if (g.nface && b.order[(size_t)CL_G * (c0 + k) + m] == CL_DUMMY) continue;
             const double4 v = p[m];
             l[0] = fmin(l[0], v.x); h[0] = fmax(h[0], v.x);
             l[1] = fmin(l[1], v.y); h[1] = fmax(h[1], v.y);

@@ -89,6 +89,8 @@ struct msm_amd_handle {
     // (ClusterBuffers::acc_slots); the stage entry points, whose d_acc is the caller's to read after every stage, do not.
     double4 *acc_slots = nullptr;
     int opt_acc_slots = 1;      // 0: the pair kernels scatter into the caller's array themselves (A/B)
+    int opt_face_cut = 1;       // slab ranks: clusters never mix owned particles and halo copies (0: cut every 8 particles, A/B)
+    bool face_room = false;     // the cluster arrays were sized for the padded clusters at the faces (a handle created as a slab rank)
     bool fused_acc = false;     // set for the duration of a whole evaluation that qualifies
     // msm_amd_eval_reuse: the pair set and its lists (allocated by the first call, sized for its skin)
     ReuseBuffers rs = {};
@@ -194,6 +196,27 @@ static int dalloc(T **p, size_t n) {
         return MSM_AMD_ENOMEM;
     }
     return MSM_AMD_OK;
+}
+
+// Where ownership changes along a column of a slab rank's sort (ClusterGeom::face): the fine bins of the slab's two
+// faces.  A periodic slab that touches the end of the cell has its lower (upper) halo at the other end: its second
+// face is put in the middle of the planes it does not hold, so that no cluster reaches from one halo to the other.
+static void set_slab_faces(msm_amd_handle *h) {
+    const msm_amd_plan_desc &d = h->hp.d;
+    ClusterGeom &cg = h->clg;
+    cg.nface = 0;
+    cg.face[0] = cg.face[1] = cg.nzf;
+    if (!h->opt_face_cut || !h->face_room || d.nzplanes >= d.M[2] || cg.kx <= 0 || cg.kz <= 0 || cg.sort_blocks <= 0 || h->small_box) return;
+    const int Mz = d.M[2], z0 = d.zplane0, z1 = d.zplane0 + d.nzplanes;
+    const int mid = ((z1 + (Mz - d.nzplanes) / 2) % Mz) * cg.kz; // centre of the planes of the other ranks
+    int a = z0 > 0 ? z0 * cg.kz : (d.open_boundary ? cg.nzf : mid);
+    int b = z1 < Mz ? z1 * cg.kz : (d.open_boundary ? cg.nzf : mid);
+    if (a > b) std::swap(a, b);
+    if (a <= 0) a = cg.nzf; // (a face at the first bin cuts nothing)
+    if (a > b) std::swap(a, b);
+    cg.face[0] = a;
+    cg.face[1] = b;
+    cg.nface = 2;
 }
 
 static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, void *stream, msm_amd_handle **out) {
@@ -346,6 +369,8 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         }
         cg.nbins = cg.ncols * cg.nzf;
         cg.max_clusters = (N + CL_G - 1) / CL_G + cg.ncols;
+        // (a slab rank starts new clusters at the faces of its slab: up to two padded clusters more per column)
+        if (d.nzplanes < d.M[2] && cg.kx > 0) { cg.max_clusters += 2 * cg.ncols; h->face_room = true; }
         {
             // list length: halves for the later / earlier neighbour clusters, the tail of the second half for shifted
             // ones.  Expected neighbours of a cluster = clusters in the volume within a of a cube of its size,
@@ -397,6 +422,7 @@ static int create_impl(const msm_amd_plan_desc *plan, bool literal, int device, 
         if (const char *e = getenv("MSM_AMD_SORT")) h->opt_sort_two_level = atoi(e) != 0; // A/B: 0 = one global counter per fine bin
         cg.sort_blocks = (h->opt_sort_two_level && cg.ncols <= 16384 && cg.nzf <= 4096) ? std::max(1, std::min(512, (N + 2047) / 2048)) : 0;
         h->clg.sort_blocks = cg.sort_blocks;
+        set_slab_faces(h);
         if (cg.sort_blocks) {
             DA(cb.hist, (size_t)cg.sort_blocks * cg.ncols); DA(cb.coltotal, cg.ncols); DA(cb.cpstart, cg.ncols + 1);
             DA(cb.bps, N); DA(cb.bkey, N);
@@ -585,6 +611,7 @@ extern "C" int msm_amd_set_planes(msm_amd_handle *h, int zplane0, int nzplanes) 
     h->hp.d.nzplanes = nzplanes;
     h->sp.z0 = zplane0;
     h->sp.nz = nzplanes;
+    set_slab_faces(h);
     return MSM_AMD_OK;
 }
 
@@ -617,6 +644,7 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "anterp_cols")) { h->sopt.anterp_cols = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "energy_fused")) { h->opt_energy_fused = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "acc_slots")) { h->opt_acc_slots = value != 0; return MSM_AMD_OK; }
+    if (!strcmp(key, "face_cut")) { h->opt_face_cut = value != 0; set_slab_faces(h); return MSM_AMD_OK; }
     if (!strcmp(key, "overlap")) { h->opt_overlap = value; return MSM_AMD_OK; }
     if (!strcmp(key, "slab_own_stream")) { h->opt_slab_own_stream = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "slab_overlap")) { h->opt_slab_overlap = value; return MSM_AMD_OK; }

@@ -88,10 +88,16 @@ struct ClusterGeom {
     double origin[3];    // corner of the cell (0 for periodic plans): positions enter as r - origin
     int sort_blocks;     // workgroups of the two-level sort (0: the sort with one counter per fine bin is used)
     int n_owned;         // particles with original index >= n_owned are halo copies; CL_ALL_OWNED when there are none
+    // A slab rank (grid-aligned columns, two-level sort): the fine bins at which ownership changes along a column, in
+    // ascending order (nzf = none).  The sort starts a new cluster there (the cluster before it is padded), so that no
+    // cluster mixes owned particles and halo copies; a column is given nface clusters more than its particles need.
+    int nface;
+    int face[2];
 };
 #define CL_ALL_OWNED 0x7fffffff
 struct ClusterBuffers {
-    int *count, *start;         // per fine bin (start has nbins + 1 entries)
+    int *count, *start;         // per fine bin (start has nbins + 1 entries): particles in earlier bins; with ClusterGeom::nface
+                                // the slot of the bin's first particle instead (padding at the faces included)
     int *colncl, *clstart;      // clusters per column and their exclusive scan (ncols + 1; last = cluster count)
     int *order;                 // original particle index per slot, CL_DUMMY for padding
     double4 *ps;                // (x, y, z, q) per slot, absolute coordinates in [0, A)

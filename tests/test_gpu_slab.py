@@ -402,10 +402,16 @@ def test_slab_step_options_keep_the_bits(rank):
              {"conv_tile_planes": 6}, {"conv_tile_planes": 8}, {"conv_tile_planes": 9},
              {"conv_tile_planes": 10}, {"conv_tile_planes": 12, "slab_overlap": 1}, {"pair_wpb": 2}, {"pair_wpb": 4},
              {"list_wpb": 1}, {"pair_lds_pad": 17408}, {"acc_slots": 0}, {"energy_fused": 1}]
+    # (face_cut 0 changes the clusters, hence the order of the sums: compared to rounding below)
     for opts in cases:
         acc, sums = _one_rank_steps(rank, world, opts)
         assert torch.equal(acc, ref_acc), opts
         assert torch.equal(sums, ref_sums), opts
+    # clusters cut at the faces of the slab (default) and every 8 particles whatever they are: other clusters, other
+    # order of the sums, the same result to rounding
+    acc, sums = _one_rank_steps(rank, world, {"face_cut": 0})
+    assert float((acc - ref_acc).abs().max()) <= 1e-12 * float(ref_acc.abs().max())
+    assert float(((sums - ref_sums).abs() / ref_sums.abs().clamp_min(1e-300)).max()) <= 1e-11
 
 
 def test_pair_trace_hook():
