@@ -412,6 +412,15 @@ def test_slab_step_options_keep_the_bits(rank):
     acc, sums = _one_rank_steps(rank, world, {"face_cut": 0})
     assert float((acc - ref_acc).abs().max()) <= 1e-12 * float(ref_acc.abs().max())
     assert float(((sums - ref_sums).abs() / ref_sums.abs().clamp_min(1e-300)).max()) <= 1e-11
+    # the taps of a level-0 tile shared out over 3 and over 5 workgroups (the most the partial-sum buffer holds): the
+    # partial sums are added in another order; more shares than that are refused
+    for split in (3, 5):
+        acc, sums = _one_rank_steps(rank, world, {"conv_split": split})
+        assert float((acc - ref_acc).abs().max()) <= 1e-12 * float(ref_acc.abs().max()), split
+        assert float(((sums - ref_sums).abs() / ref_sums.abs().clamp_min(1e-300)).max()) <= 1e-11, split
+    import msm_amd
+    with pytest.raises(msm_amd.MsmAmdError):
+        _one_rank_steps(rank, world, {"conv_split": 6})
 
 
 def test_pair_trace_hook():
