@@ -1218,7 +1218,7 @@ __device__ __forceinline__ void direct_one_cluster(const ClusterGeom &g, const C
     // cluster comes first, and not at all on the other side
     // onesided (a slab rank whose other clusters are evaluated by k_pair_clusters_filtered): the same for the pairs of
     // two clusters whose particles are all owned, half for the others
-    double u1 = 0, uh = 0, unone = 0, fx = 0, fy = 0, fz = 0;
+    double u1 = 0, uh = 0, fx = 0, fy = 0, fz = 0;
     const bool ifull = onesided && b.fbox[2 * (size_t)icl].w != 0.f;
     // (a, a2_enum: reach of the walk over the sort's bins - the cutoff, or more when the particles have moved since the
     // sort; the pair arithmetic applies the cutoff itself)
@@ -1233,7 +1233,14 @@ __device__ __forceinline__ void direct_one_cluster(const ClusterGeom &g, const C
             const double4 q = pj[(size_t)CL_G * j];
             if (cd == CL_NOSHIFT) {
                 if (j == icl) cl_slot<P, true>(I.x, I.y, I.z, q, pp, ii != jj, uh, fx, fy, fz);
-                else cl_slot<P, false>(I.x, I.y, I.z, q, pp, true, !one ? uh : (j > icl ? u1 : unone), fx, fy, fz);
+                else {
+                    // (the sum the pair's energy goes to is picked by value: a reference picked at run time would
+                    // put all three sums, and whatever is captured with them, into scratch memory)
+                    double ut = 0.0;
+                    cl_slot<P, false>(I.x, I.y, I.z, q, pp, true, ut, fx, fy, fz);
+                    uh += one ? 0.0 : ut;
+                    u1 += one && j > icl ? ut : 0.0;
+                }
             } else {
                 double sx, sy, sz;
                 shift_of_code(g, cd, sx, sy, sz);
@@ -1569,7 +1576,8 @@ void launch_reuse_pairs(hipStream_t st, const ClusterGeom &g, const ClusterBuffe
 }
 
 void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double *acc,
-                          double *epart, int variant, int n_total, hipEvent_t *ev, int max_wgs, hipEvent_t after_lists, int lds_pad_wpe) {
+                          double *epart, int variant, int n_total, hipEvent_t *ev, int max_wgs, hipEvent_t after_lists, int lds_pad_wpe,
+                          const std::function<void()> *between) {
     const double a = sqrt(pp.a2);
     // A/B: unused LDS per workgroup, waves per workgroup of the list-walking kernel (0: one), of the list build (0: four)
     const int lds_pad = lds_pad_wpe & 0xFFFFF, wpb = (lds_pad_wpe >> 20) & 0xF, list_wpb = (lds_pad_wpe >> 24) & 0xF;
@@ -1578,6 +1586,7 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
     const int half = pp.n_owned >= n_total ? 1 : 0; // every particle owned: pair energies are taken from one side
     if (variant == 1) {
         if (after_lists) hipEventRecord(after_lists, st); // no lists: nothing to wait for
+        if (between) (*between)();
         if (pp.p == 4) hipLaunchKernelGGL((k_pair_clusters_direct<4>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart, half);
         else hipLaunchKernelGGL((k_pair_clusters_direct<6>), dim3(nblk), dim3(256), 0, st, g, b, pp, a, acc, epart, half);
         return;
@@ -1593,6 +1602,7 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
         else hipLaunchKernelGGL(k_cl_list<true>, dim3(nblk), dim3(256), 0, st, g, b, a, pp.a2, pp.n_owned, (const int *)nullptr);
     }
     if (after_lists) hipEventRecord(after_lists, st); // lets another stream start beside the pair kernel, not beside the list build
+    if (between) (*between)();
 #define LAUNCH_PC(P, HALF, U)                                                                                  \
     do {                                                                                                       \
         if (ev) hipEventRecord(ev[0], st);                                                                     \

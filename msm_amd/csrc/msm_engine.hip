@@ -114,6 +114,7 @@ struct msm_amd_handle {
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr; // fork / join of the coarse-level branch of the grid stage (on stream_b)
     hipEvent_t pairs_after = nullptr; // set for one msm_amd_stage_pairs call: recorded between the list build and the pair kernel
+    std::function<void()> pairs_between; // set for one msm_amd_stage_pairs call: called between the list build and the pair kernel
     int opt_conv_sym = 2;       // tiled convolution: mirror columns of a stencil share their multiplications (2: and 16 outputs per thread; 0: off)
     int opt_transfer_chain = 1; // two prolongations per launch where the grids allow it
     int opt_conv_tile_planes = 0; // slab ranks: planes per tile of k_conv_split (0: chosen per launch)
@@ -735,8 +736,10 @@ extern "C" int msm_amd_stage_pairs(msm_amd_handle *h, double *d_acc) {
         ClusterBuffers cb = h->clb;
         cb.acc_slots = h->fused_acc ? h->acc_slots : nullptr;
         launch_pair_clusters(h->stream, h->clg, cb, h->pp, d_acc, h->epart, h->opt_pair_variant - 5, h->N,
-                             h->profiling ? h->ev_pk : nullptr, h->pair_wgs_now, h->pairs_after, h->opt_pair_lds_pad | (h->opt_pair_wpb << 20) | (h->opt_list_wpb << 24));
+                             h->profiling ? h->ev_pk : nullptr, h->pair_wgs_now, h->pairs_after, h->opt_pair_lds_pad | (h->opt_pair_wpb << 20) | (h->opt_list_wpb << 24),
+                             h->pairs_between ? &h->pairs_between : nullptr);
         h->pairs_after = nullptr;
+        h->pairs_between = nullptr;
         h->pk_recorded = h->profiling && h->opt_pair_variant != 6;
         h->nepart = h->clg.max_clusters;
     } else {
@@ -989,7 +992,8 @@ static int grid_front(msm_amd_handle *h, const msm_amd_collectives *coll) {
 
 static int ensure_stream_b(msm_amd_handle *h);
 // part: 0 the whole stage; 1 only the branch of the coarser levels (restrictions, their convolutions, top level,
-// prolongations down to level 1); 2 only what is left after it (level-0 convolution, last prolongation)
+// prolongations down to level 1); 2 only what is left after it (level-0 convolution, last prolongation); 3 and 4: the
+// two halves of 2, the level-0 convolution (which needs no coarser level) and the last prolongation
 static int grid_stage(msm_amd_handle *h, bool front_done, int part = 0) {
     const msm_amd_plan_desc &d = h->hp.d;
     const int L = d.L, p = d.p;
@@ -1049,12 +1053,16 @@ static int grid_stage(msm_amd_handle *h, bool front_done, int part = 0) {
             top_level(h);
             prolong_to_level1(h);
         } else {
-            mark(h, T_CONV);
-            convolve_ranges(h, fine);
-            mark(h, T_TOP);
-            mark(h, T_PRO);
-            if (slab && d.nzplanes + p < d.M[2]) prolong_level_add(h, 0, h->ge[1], h->ge[0], d.zplane0 - p / 2, d.nzplanes + p);
-            else prolong_level_add(h, 0, h->ge[1], h->ge[0]);
+            if (part != 4) {
+                mark(h, T_CONV);
+                convolve_ranges(h, fine);
+            }
+            if (part != 3) {
+                mark(h, T_TOP);
+                mark(h, T_PRO);
+                if (slab && d.nzplanes + p < d.M[2]) prolong_level_add(h, 0, h->ge[1], h->ge[0], d.zplane0 - p / 2, d.nzplanes + p);
+                else prolong_level_add(h, 0, h->ge[1], h->ge[0]);
+            }
         }
         HIPCHK(hipGetLastError());
         return MSM_AMD_OK;
@@ -1586,7 +1594,12 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
     const size_t plane = (size_t)d.M[0] * d.M[1];
     bool coarse_on_b = false;
     // 3: the whole grid stage behind the exchange on the second stream, 4: and the anterpolation before it (A/B)
-    const bool grid_on_b = two && ov >= 3 && !h->profiling, anterp_on_b = grid_on_b && ov == 4;
+    // 5: as 2, but the first stream convolves level 0 between the list build and the pair kernel, as soon as the exchanged
+    // level-0 charges are there: whatever is queued beside the pair kernel gets the compute units its one-wave workgroups
+    // leave over, which is next to nothing until the last of them has started - a level-0 convolution queued a few
+    // microseconds before the pair kernel took 61 us in one step and 200 in the next; ahead of it, it takes its 48
+    const bool conv_first = two && ov == 5 && d.L >= 2 && !h->profiling;
+    const bool grid_on_b = two && (ov == 3 || ov == 4) && !h->profiling, anterp_on_b = grid_on_b && ov == 4;
     if ((rc = msm_amd_stage_bin(h, d_r, d_q))) return rc;
     if (!anterp_on_b && (rc = msm_amd_stage_anterpolate(h))) return rc;
     if (two) {
@@ -1623,21 +1636,37 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
                 set_error("slab step: the halo exchange of the level-0 charges failed");
                 rc = MSM_AMD_EHIP;
             }
+            // (the level-0 convolution needs nothing beyond this exchange)
+            if (!rc && conv_first && hipEventRecord(h->ev_pairs, b) != hipSuccess) { set_error("slab step: hipEventRecord failed"); rc = MSM_AMD_EHIP; }
             if (!rc) rc = grid_front(h, coll);
+        }
+        if (!rc && conv_first && xmode != MSM_AMD_SLAB_HALO && hipEventRecord(h->ev_pairs, b) != hipSuccess) {
+            set_error("slab step: hipEventRecord failed");
+            rc = MSM_AMD_EHIP;
         }
         // 2: the chain of the coarser levels (restrictions, their convolutions, top level, prolongations down to level 1:
         // small kernels that each last as long as a launch) follows the exchange on the second stream, beside the pair
         // sum; the first stream is left with the level-0 convolution and the last prolongation
-        coarse_on_b = two && ov == 2 && d.L >= 2 && !h->profiling;
+        coarse_on_b = two && (ov == 2 || conv_first) && d.L >= 2 && !h->profiling;
         if (!rc && grid_on_b) rc = grid_stage(h, xmode == MSM_AMD_SLAB_HALO, 0);
         else if (!rc && coarse_on_b) rc = grid_stage(h, xmode == MSM_AMD_SLAB_HALO, 1);
         if (!rc && two && hipEventRecord(h->ev_join, b) != hipSuccess) { set_error("slab step: hipEventRecord failed"); rc = MSM_AMD_EHIP; }
         h->stream = a;
         if (rc) return rc;
     }
-    if ((rc = msm_amd_stage_pairs(h, d_acc))) return rc;
+    int conv_rc = MSM_AMD_OK;
+    if (conv_first) {
+        const bool halo = xmode == MSM_AMD_SLAB_HALO;
+        h->pairs_between = [h, a, halo, &conv_rc]() {
+            if (hipStreamWaitEvent(a, h->ev_pairs, 0) != hipSuccess) { set_error("slab step: hipStreamWaitEvent failed"); conv_rc = MSM_AMD_EHIP; return; }
+            conv_rc = grid_stage(h, halo, 3);
+        };
+    }
+    rc = msm_amd_stage_pairs(h, d_acc);
+    h->pairs_between = nullptr;
+    if (rc || (rc = conv_rc)) return rc;
     if (two) HIPCHK(hipStreamWaitEvent(a, h->ev_join, 0));
-    if (!(slab && grid_on_b) && (rc = grid_stage(h, slab && xmode == MSM_AMD_SLAB_HALO, coarse_on_b ? 2 : 0))) return rc;
+    if (!(slab && grid_on_b) && (rc = grid_stage(h, slab && xmode == MSM_AMD_SLAB_HALO, conv_first ? 4 : coarse_on_b ? 2 : 0))) return rc;
     if ((rc = msm_amd_stage_interpolate(h, d_acc))) return rc;
     if ((rc = queue_energies(h, true))) return rc;
     if (coll && world > 1 && coll->all_reduce_sum(coll->ctx, h->d_energies, 5, (void *)a)) {

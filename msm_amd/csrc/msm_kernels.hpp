@@ -1,5 +1,6 @@
 // Device-side data structures and launch wrappers of the gfx950 kernels.
 #pragma once
+#include <functional>
 #include <hip/hip_runtime.h>
 
 namespace msm {
@@ -131,7 +132,9 @@ void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, i
 // after_lists (optional): an event recorded between the list build and the pair kernel
 void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double *acc,
                           double *epart, int variant, int n_total, hipEvent_t *ev, int max_wgs = 0, hipEvent_t after_lists = nullptr,
-                          int lds_pad = 0); // lds_pad: unused LDS bytes per workgroup of the list-walking kernel (caps the waves per SIMD)
+                          int lds_pad = 0, // lds_pad: unused LDS bytes per workgroup of the list-walking kernel (caps the waves per SIMD)
+                          const std::function<void()> *between = nullptr); // called between the list build and the pair kernel: what it
+                                                                           // queues on st runs there
 
 // ---- neighbour structures kept over several evaluations (msm_amd_eval_reuse) ----
 // The "pair set": the cluster order of the last rebuild, frozen (slots, original indices, fine-bin prefix sums), with

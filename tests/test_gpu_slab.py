@@ -361,7 +361,7 @@ class _NoDist:
         return "nccl"
 
 
-def _one_rank_steps(rank, world, options, steps=3, kind="halo"):
+def _one_rank_steps(rank, world, options, steps=3, kind="halo", own_stream=False):
     """`steps` evaluations of one rank of `world` with collectives that move nothing: the planes of the other ranks keep
     what they held, which depends only on the rank's own history, so two runs of the same history give the same bits
     whichever stream or launch shape the engine's options pick."""
@@ -376,12 +376,17 @@ def _one_rank_steps(rank, world, options, steps=3, kind="halo"):
     else:                   # a = 0.07 on the 96^3 grid: 16 halo planes do not fit a slab of 12, the all-gather it is
         N, desc = _plan(msm_amd, ("explicit", 100000, 6, 4, 96, {"halo": 0.04, "wide": 5.0 / 96, "allgather": 0.07}[kind]))
         r, q = O.neutral_system(N, (1.0, 1.0, 1.0), seed=47)
-    s = SlabRank(torch, _NoDist(), msm_amd, desc, r, q, rank, world, 0, perturb=False, collectives=NullCollectives(rank, world))
-    assert s.eng.slab_exchange_mode(world, 0) == {"halo": 2, "wide": 2, "allgather": 1, "open": 3}[kind]
-    for k, v in options.items():
-        s.eng.set_option(k, v)
-    for _ in range(steps):
-        s.step(want_energies=False)
+    # own_stream: the rank on a stream of the caller's (the engine created on it, the stream current around every call)
+    # instead of the legacy default stream
+    side = torch.cuda.Stream() if own_stream else None
+    with torch.cuda.stream(side):
+        s = SlabRank(torch, _NoDist(), msm_amd, desc, r, q, rank, world, 0, perturb=False, collectives=NullCollectives(rank, world),
+                     stream=side)
+        assert s.eng.slab_exchange_mode(world, 0) == {"halo": 2, "wide": 2, "allgather": 1, "open": 3}[kind]
+        for k, v in options.items():
+            s.eng.set_option(k, v)
+        for _ in range(steps):
+            s.step(want_energies=False)
     torch.cuda.synchronize()
     out = s.acc[:s.n_own].clone(), s.sums.clone()
     s.eng.close()      # (and with it the handle's two streams: the cases of a test do not pile them up)
@@ -399,12 +404,18 @@ def test_slab_step_options_keep_the_bits(rank):
     ref_acc, ref_sums = _one_rank_steps(rank, world, {})
     assert torch.isfinite(ref_acc).all() and float(ref_acc.abs().max()) > 0
     cases = [{"slab_overlap": 0}, {"slab_overlap": 1}, {"slab_overlap": 2}, {"slab_overlap": 3}, {"slab_overlap": 4},
+             {"slab_overlap": 5},
              {"conv_tile_planes": 6}, {"conv_tile_planes": 8}, {"conv_tile_planes": 9},
              {"conv_tile_planes": 10}, {"conv_tile_planes": 12, "slab_overlap": 1}, {"pair_wpb": 2}, {"pair_wpb": 4},
              {"list_wpb": 1}, {"pair_lds_pad": 17408}, {"acc_slots": 0}, {"energy_fused": 1}]
     # (face_cut 0 changes the clusters, hence the order of the sums: compared to rounding below)
     for opts in cases:
         acc, sums = _one_rank_steps(rank, world, opts)
+        assert torch.equal(acc, ref_acc), opts
+        assert torch.equal(sums, ref_sums), opts
+    # the rank on a stream of the caller's instead of the default stream (the step then stays on the stream it is given)
+    for opts in ({}, {"slab_overlap": 2}, {"slab_overlap": 5}):
+        acc, sums = _one_rank_steps(rank, world, opts, own_stream=True)
         assert torch.equal(acc, ref_acc), opts
         assert torch.equal(sums, ref_sums), opts
     # clusters cut at the faces of the slab (default) and every 8 particles whatever they are: other clusters, other
@@ -462,7 +473,7 @@ def test_slab_step_streams_keep_the_bits_other_exchanges(kind, world, rank):
     import torch
     ref_acc, ref_sums = _one_rank_steps(rank, world, {}, kind=kind)
     assert torch.isfinite(ref_acc).all() and float(ref_acc.abs().max()) > 0
-    for opts in ({"slab_overlap": 0}, {"slab_overlap": 1}, {"slab_overlap": 2}, {"slab_overlap": 3}, {"slab_overlap": 4},
+    for opts in ({"slab_overlap": 0}, {"slab_overlap": 1}, {"slab_overlap": 2}, {"slab_overlap": 3}, {"slab_overlap": 4}, {"slab_overlap": 5},
                  {"conv_tile_planes": 8}, {"pair_wpb": 4}):
         acc, sums = _one_rank_steps(rank, world, opts, kind=kind)
         assert torch.equal(acc, ref_acc), (kind, opts)

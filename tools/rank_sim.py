@@ -17,8 +17,13 @@ desc = msm_amd.plan_auto(N, (1.0, 1.0, 1.0), p, 10, 4.0, 0)
 # argv[4]: exchange mode (0 auto, 1 all-gather, 2 halo); argv[5] == "py": the stage-by-stage Python step instead of the C step
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 c_step = not (len(sys.argv) > 5 and sys.argv[5] == "py")
+# RANK_SIM_STREAM=default: the engine on the legacy default stream (the step then moves to streams of its own and back);
+# otherwise on a stream of the caller's, as a time-stepping code that owns its stream would create it
+side = None if os.environ.get("RANK_SIM_STREAM", "side") == "default" else torch.cuda.Stream()
+if side is not None:
+    torch.cuda.set_stream(side)
 s = SlabRank(torch, FakeDist(), msm_amd, desc, r, q, RANK, W, 0, perturb=True, mode=mode,
-             collectives=NullCollectives(RANK, W) if W > 1 else None, c_step=c_step)
+             collectives=NullCollectives(RANK, W) if W > 1 else None, c_step=c_step, stream=side)
 for kv in filter(None, (sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else "").split(",")):   # engine options: key=value,key=value
     k, v = kv.split("=")
     s.eng.set_option(k, int(v))
