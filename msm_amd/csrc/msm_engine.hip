@@ -115,6 +115,7 @@ struct msm_amd_handle {
     hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr; // fork / join of the coarse-level branch of the grid stage (on stream_b)
     hipEvent_t pairs_after = nullptr; // set for one msm_amd_stage_pairs call: recorded between the list build and the pair kernel
     std::function<void()> pairs_between; // set for one msm_amd_stage_pairs call: called between the list build and the pair kernel
+    hipEvent_t ev_restricted = nullptr;  // set for one grid stage: recorded behind its restrictions
     int opt_conv_sym = 2;       // tiled convolution: mirror columns of a stencil share their multiplications (2: and 16 outputs per thread; 0: off)
     int opt_transfer_chain = 1; // two prolongations per launch where the grids allow it
     int opt_conv_tile_planes = 0; // slab ranks: planes per tile of k_conv_split (0: chosen per launch)
@@ -132,6 +133,7 @@ struct msm_amd_handle {
     int pair_wgs_now = 0;     // A/B: cap on the workgroups of the pair kernel (0: one workgroup per four clusters; measured
                               // slower at 2, 3 and 4 workgroups per CU, and kernels of a second stream gain nothing from the room)
     int opt_slab_own_stream = 1; // slab step of a handle on the default stream: on streams of its own (0: as given, A/B)
+    int opt_conv_leads = 1;    // slab step with the grid stage on the second stream: the pair kernel starts behind the restrictions (0: A/B)
     int opt_slab_overlap = -1; // slab step, what runs on a second stream beside the list build and the pair sum: 0 nothing (one
                               // stream: for several processes sharing one GPU, where cross-stream waits were seen to stall);
                               // 1 the charge exchange; 2 and the chain of the coarser levels behind it (-16 / -12 / -23 us at
@@ -648,6 +650,7 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "face_cut")) { h->opt_face_cut = value != 0; set_slab_faces(h); return MSM_AMD_OK; }
     if (!strcmp(key, "overlap")) { h->opt_overlap = value; return MSM_AMD_OK; }
     if (!strcmp(key, "slab_own_stream")) { h->opt_slab_own_stream = value != 0; return MSM_AMD_OK; }
+    if (!strcmp(key, "conv_leads")) { h->opt_conv_leads = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "slab_overlap")) { h->opt_slab_overlap = value; return MSM_AMD_OK; }
     if (!strcmp(key, "conv_split")) { // shares of a level-0 tile's taps: conv_part holds the partial sums of shares 1..4
         if (value < 0 || value > 5) { set_error("conv_split: 0 (off), 1 (chosen per launch) or 2..5 shares"); return MSM_AMD_EINVAL; }
@@ -1079,6 +1082,11 @@ static int grid_stage(msm_amd_handle *h, bool front_done, int part = 0) {
         h->stream = h->stream_b; // the helpers below enqueue on the handle's stream
     }
     for (int l = front_done ? 1 : 0; l + 1 < L; l++) restrict_level(h, l, h->gq[l], h->gq[l + 1]);
+    if (h->ev_restricted) {
+        hipError_t e = hipEventRecord(h->ev_restricted, h->stream);
+        h->ev_restricted = nullptr;
+        if (e != hipSuccess) { set_error("hipEventRecord failed: %s", hipGetErrorString(e)); return MSM_AMD_EHIP; }
+    }
     if (!two) {
         mark(h, T_CONV);
         std::vector<PlaneRange> all(fine);
@@ -1592,7 +1600,7 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
     }
     hipStream_t a = h->stream, b = two ? h->stream_b : h->stream;
     const size_t plane = (size_t)d.M[0] * d.M[1];
-    bool coarse_on_b = false;
+    bool coarse_on_b = false, wait_before_pairs = false;
     // 3: the whole grid stage behind the exchange on the second stream, 4: and the anterpolation before it (A/B)
     // 5: as 2, but the first stream convolves level 0 between the list build and the pair kernel, as soon as the exchanged
     // level-0 charges are there: whatever is queued beside the pair kernel gets the compute units its one-wave workgroups
@@ -1648,13 +1656,28 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
         // small kernels that each last as long as a launch) follows the exchange on the second stream, beside the pair
         // sum; the first stream is left with the level-0 convolution and the last prolongation
         coarse_on_b = two && (ov == 2 || conv_first) && d.L >= 2 && !h->profiling;
+        // The level-0 convolution, the largest kernel of the second stream, has to be under way before the pair kernel
+        // is: whatever is queued beside the pair kernel gets the compute units its one-wave workgroups leave over, next
+        // to nothing until the last of them has started (a convolution that started 2 us after the pair kernel took 200 us
+        // instead of 61 and the step 30 us longer, in a quarter of the steps).  The pair kernel therefore waits for the
+        // restrictions in front of the convolution - as a rule they have long finished beside the list build.
+        const bool conv_leads = grid_on_b && h->opt_conv_leads && d.L >= 2;
+        if (conv_leads) h->ev_restricted = h->ev_pairs;
         if (!rc && grid_on_b) rc = grid_stage(h, xmode == MSM_AMD_SLAB_HALO, 0);
+        const bool lead_recorded = conv_leads && !rc && h->ev_restricted == nullptr;
+        h->ev_restricted = nullptr;
+        if (lead_recorded) wait_before_pairs = true;
         else if (!rc && coarse_on_b) rc = grid_stage(h, xmode == MSM_AMD_SLAB_HALO, 1);
         if (!rc && two && hipEventRecord(h->ev_join, b) != hipSuccess) { set_error("slab step: hipEventRecord failed"); rc = MSM_AMD_EHIP; }
         h->stream = a;
         if (rc) return rc;
     }
     int conv_rc = MSM_AMD_OK;
+    if (wait_before_pairs) {
+        h->pairs_between = [h, a, &conv_rc]() {
+            if (hipStreamWaitEvent(a, h->ev_pairs, 0) != hipSuccess) { set_error("slab step: hipStreamWaitEvent failed"); conv_rc = MSM_AMD_EHIP; }
+        };
+    }
     if (conv_first) {
         const bool halo = xmode == MSM_AMD_SLAB_HALO;
         h->pairs_between = [h, a, halo, &conv_rc]() {
