@@ -838,7 +838,8 @@ __global__ __launch_bounds__(256) void k_pair_clusters(ClusterGeom g, ClusterBuf
 #define CLQ_U 4 // groups per unrolled step of the pair arithmetic (2..4 and 4..6 waves per SIMD all time the same)
 template <int P, bool HALF, int WPE = 1, int WPB = 4>
 __global__ __launch_bounds__(64 * WPB, WPE) void k_pair_clusters_filtered(ClusterGeom g, ClusterBuffers b, PairParams pp,
-                                                                double *__restrict__ acc, double *__restrict__ epart) {
+                                                                double *__restrict__ acc, double *__restrict__ epart,
+                                                                int chunk, int nchunks) {
     __shared__ double4 queue[WPB][CLQ_CAP];
     const int lane = threadIdx.x & 63, ii = lane >> 3, jj = lane & 7;
     // A workgroup takes a run of consecutive clusters (WPB per step, one per wave).  Launched with one workgroup per
@@ -852,12 +853,19 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_pair_clusters_filtered(Cluste
     // The launch covers the cluster slots the buffers can hold; the clusters there are come first, and a slab rank, which
     // is created with headroom, has 6 % fewer: the runs are dealt out over the live steps only (an XCD would else get an
     // eighth of the slots, and the last one the empty ones), the steps behind them keep their own number.
-    const int nsteps = (g.max_clusters + WPB - 1) / WPB, per = (nsteps + (int)gridDim.x - 1) / (int)gridDim.x;
+    // The kernel may be launched in several chunks, one after the other (one-wave workgroups only): chunk c takes the
+    // c-th share of the clusters there are, the last one also the empty slots behind them.  Between two chunks the
+    // kernels of another stream find free wave slots, which they do not while one launch has workgroups left to start.
+    const int nsteps = (g.max_clusters + WPB - 1) / WPB;
     const int ncl = b.clstart[g.ncols];
-    const int nlive = (ncl + WPB - 1) / WPB;
+    const int nlive_all = (ncl + WPB - 1) / WPB;
+    const int lo = nchunks > 1 ? (int)((long long)nlive_all * chunk / nchunks) : 0;
+    const int hi = nchunks > 1 && chunk + 1 < nchunks ? (int)((long long)nlive_all * (chunk + 1) / nchunks) : nsteps;
+    const int per = nchunks > 1 ? 1 : (nsteps + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nlive = min(hi, nlive_all) - lo;
     int step0 = xcd_remap(blockIdx.x, gridDim.x) * per;
-    if (per == 1) step0 = (int)blockIdx.x < nlive ? xcd_remap(blockIdx.x, nlive) : (int)blockIdx.x;
-    const int step1 = min(nsteps, step0 + per);
+    if (per == 1) step0 = lo + ((int)blockIdx.x < nlive ? xcd_remap(blockIdx.x, nlive) : (int)blockIdx.x);
+    const int step1 = min(hi, step0 + per);
     for (int step = step0; step < step1; step++) [&] {
     const int icl = __builtin_amdgcn_readfirstlane(step * WPB + (threadIdx.x >> 6));
     if (icl >= g.max_clusters) return;
@@ -1577,11 +1585,12 @@ void launch_reuse_pairs(hipStream_t st, const ClusterGeom &g, const ClusterBuffe
 
 void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double *acc,
                           double *epart, int variant, int n_total, hipEvent_t *ev, int max_wgs, hipEvent_t after_lists, int lds_pad_wpe,
-                          const std::function<void()> *between) {
+                          const std::function<void()> *between, int nchunks, const std::function<void()> *before_last) {
     const double a = sqrt(pp.a2);
     // A/B: unused LDS per workgroup, waves per workgroup of the list-walking kernel (0: one), of the list build (0: four)
     const int lds_pad = lds_pad_wpe & 0xFFFFF, wpb = (lds_pad_wpe >> 20) & 0xF, list_wpb = (lds_pad_wpe >> 24) & 0xF;
     const int nblk = (g.max_clusters + 3) / 4;
+    const int chunks = std::max(1, std::min(nchunks, 8));
     const int nwg = max_wgs > 0 ? std::min(nblk, max_wgs) : nblk; // workgroups of the list-walking kernel (it loops over its share)
     const int half = pp.n_owned >= n_total ? 1 : 0; // every particle owned: pair energies are taken from one side
     if (variant == 1) {
@@ -1614,9 +1623,16 @@ void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuf
 #define LAUNCH_PF(P, HALF)                                                                                          \
     do {                                                                                                            \
         if (ev) hipEventRecord(ev[0], st);                                                                          \
-        if (max_wgs > 0 || wpb == 4) hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF, 1, 4>), dim3(nwg), dim3(256), lds_pad, st, g, b, pp, acc, epart); \
-        else if (wpb == 2) hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF, 1, 2>), dim3((g.max_clusters + 1) / 2), dim3(128), lds_pad, st, g, b, pp, acc, epart); \
-        else hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF, (HALF ? 1 : 4), 1>), dim3(g.max_clusters), dim3(64), lds_pad, st, g, b, pp, acc, epart); \
+        if (max_wgs > 0 || wpb == 4) hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF, 1, 4>), dim3(nwg), dim3(256), lds_pad, st, g, b, pp, acc, epart, 0, 1); \
+        else if (wpb == 2) hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF, 1, 2>), dim3((g.max_clusters + 1) / 2), dim3(128), lds_pad, st, g, b, pp, acc, epart, 0, 1); \
+        else for (int c = 0; c < chunks; c++) { \
+            /* chunk c holds at most a chunks-th of the slots (+1 for the rounding); the last one everything behind the */ \
+            /* first chunks-1 shares of the fewest clusters n_total particles can make */ \
+            const int most = c + 1 < chunks ? g.max_clusters / chunks + 1 \
+                                            : g.max_clusters - (int)((long long)((n_total + CL_G - 1) / CL_G) * c / chunks); \
+            if (c + 1 == chunks && chunks > 1 && before_last) (*before_last)(); \
+            hipLaunchKernelGGL((k_pair_clusters_filtered<P, HALF, (HALF ? 1 : 4), 1>), dim3(most), dim3(64), lds_pad, st, g, b, pp, acc, epart, c, chunks); \
+        } \
         if (ev) hipEventRecord(ev[1], st);                                                                          \
     } while (0)
     if (variant == 4 && g.max_clusters < (1 << 24)) { // particle granularity, survivors split by the half of i they are near

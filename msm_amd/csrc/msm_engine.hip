@@ -112,9 +112,15 @@ struct msm_amd_handle {
     hipStream_t stream_b = nullptr;
     hipStream_t stream_a = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipEvent_t ev_energy = nullptr; // slab step: behind the all-reduce of the energy sums when that runs on the second stream
+    bool energy_on_b = false;       // the last slab step left its energy sums to the second stream
+    int opt_energy_on_b = 1;        // (0: the all-reduce on the first stream, where the next step queues behind it; A/B)
     hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr; // fork / join of the coarse-level branch of the grid stage (on stream_b)
     hipEvent_t pairs_after = nullptr; // set for one msm_amd_stage_pairs call: recorded between the list build and the pair kernel
     std::function<void()> pairs_between; // set for one msm_amd_stage_pairs call: called between the list build and the pair kernel
+    std::function<void()> pairs_before_last; // the same, before the last launch of a pair kernel launched in chunks
+    int opt_pair_chunks = 2;  // launches of the list-walking pair kernel of a slab step whose last launch waits for the second stream
+                              // (the earlier ones run while the exchanges travel; 1: one launch)
     hipEvent_t ev_restricted = nullptr;  // set for one grid stage: recorded behind its restrictions
     int opt_conv_sym = 2;       // tiled convolution: mirror columns of a stencil share their multiplications (2: and 16 outputs per thread; 0: off)
     int opt_transfer_chain = 1; // two prolongations per launch where the grids allow it
@@ -575,7 +581,7 @@ extern "C" void msm_amd_destroy(msm_amd_handle *h) {
     if (h->stream_b) {
         hipStreamSynchronize(h->stream_b);
         hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_pairs); hipEventDestroy(h->ev_join);
-        hipEventDestroy(h->ev_gfork); hipEventDestroy(h->ev_gjoin);
+        hipEventDestroy(h->ev_gfork); hipEventDestroy(h->ev_gjoin); hipEventDestroy(h->ev_energy);
         hipStreamDestroy(h->stream_b);
     }
     if (h->stream_a) {
@@ -650,6 +656,8 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "face_cut")) { h->opt_face_cut = value != 0; set_slab_faces(h); return MSM_AMD_OK; }
     if (!strcmp(key, "overlap")) { h->opt_overlap = value; return MSM_AMD_OK; }
     if (!strcmp(key, "slab_own_stream")) { h->opt_slab_own_stream = value != 0; return MSM_AMD_OK; }
+    if (!strcmp(key, "energy_on_b")) { h->opt_energy_on_b = value != 0; return MSM_AMD_OK; }
+    if (!strcmp(key, "pair_chunks")) { if (value >= 1 && value <= 8) { h->opt_pair_chunks = value; return MSM_AMD_OK; } }
     if (!strcmp(key, "conv_leads")) { h->opt_conv_leads = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "slab_overlap")) { h->opt_slab_overlap = value; return MSM_AMD_OK; }
     if (!strcmp(key, "conv_split")) { // shares of a level-0 tile's taps: conv_part holds the partial sums of shares 1..4
@@ -740,9 +748,11 @@ extern "C" int msm_amd_stage_pairs(msm_amd_handle *h, double *d_acc) {
         cb.acc_slots = h->fused_acc ? h->acc_slots : nullptr;
         launch_pair_clusters(h->stream, h->clg, cb, h->pp, d_acc, h->epart, h->opt_pair_variant - 5, h->N,
                              h->profiling ? h->ev_pk : nullptr, h->pair_wgs_now, h->pairs_after, h->opt_pair_lds_pad | (h->opt_pair_wpb << 20) | (h->opt_list_wpb << 24),
-                             h->pairs_between ? &h->pairs_between : nullptr);
+                             h->pairs_between ? &h->pairs_between : nullptr, h->pairs_before_last ? h->opt_pair_chunks : 1,
+                             h->pairs_before_last ? &h->pairs_before_last : nullptr);
         h->pairs_after = nullptr;
         h->pairs_between = nullptr;
+        h->pairs_before_last = nullptr;
         h->pk_recorded = h->profiling && h->opt_pair_variant != 6;
         h->nepart = h->clg.max_clusters;
     } else {
@@ -1138,6 +1148,10 @@ extern "C" int msm_amd_stage_interpolate(msm_amd_handle *h, double *d_acc) {
 }
 
 static int queue_energies(msm_amd_handle *h, bool raw = false) {
+    if (h->energy_on_b) { // the sums of the last slab step may still be with the second stream: they are about to be overwritten
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_energy, 0));
+        h->energy_on_b = false;
+    }
     const msm_amd_plan_desc &d = h->hp.d;
     const int L = d.L;
     const size_t plane = (size_t)d.M[0] * d.M[1];
@@ -1239,6 +1253,7 @@ static int ensure_stream_b(msm_amd_handle *h) {
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_gfork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_gjoin, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_energy, hipEventDisableTiming));
     return MSM_AMD_OK;
 }
 
@@ -1674,9 +1689,12 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
     }
     int conv_rc = MSM_AMD_OK;
     if (wait_before_pairs) {
-        h->pairs_between = [h, a, &conv_rc]() {
+        auto wait = [h, a, &conv_rc]() {
             if (hipStreamWaitEvent(a, h->ev_pairs, 0) != hipSuccess) { set_error("slab step: hipStreamWaitEvent failed"); conv_rc = MSM_AMD_EHIP; }
         };
+        // in several launches, only the last one waits: the earlier ones run while the exchanges travel
+        if (h->opt_pair_chunks > 1) h->pairs_before_last = wait;
+        else h->pairs_between = wait;
     }
     if (conv_first) {
         const bool halo = xmode == MSM_AMD_SLAB_HALO;
@@ -1687,14 +1705,30 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
     }
     rc = msm_amd_stage_pairs(h, d_acc);
     h->pairs_between = nullptr;
+    h->pairs_before_last = nullptr;
     if (rc || (rc = conv_rc)) return rc;
     if (two) HIPCHK(hipStreamWaitEvent(a, h->ev_join, 0));
     if (!(slab && grid_on_b) && (rc = grid_stage(h, slab && xmode == MSM_AMD_SLAB_HALO, conv_first ? 4 : coarse_on_b ? 2 : 0))) return rc;
     if ((rc = msm_amd_stage_interpolate(h, d_acc))) return rc;
     if ((rc = queue_energies(h, true))) return rc;
-    if (coll && world > 1 && coll->all_reduce_sum(coll->ctx, h->d_energies, 5, (void *)a)) {
-        set_error("slab step: the all-reduce of the energy sums failed");
-        return MSM_AMD_EHIP;
+    // The five sums are added over the ranks on the second stream when the step has one: nothing of the next step waits
+    // for them (its own sums are written behind its join with the second stream, which works through its queue in
+    // order), only msm_amd_slab_energies does.
+    h->energy_on_b = false;
+    if (coll && world > 1) {
+        const bool on_b = two && h->opt_energy_on_b;
+        if (on_b) {
+            HIPCHK(hipEventRecord(h->ev_fork, a));
+            HIPCHK(hipStreamWaitEvent(b, h->ev_fork, 0));
+        }
+        if (coll->all_reduce_sum(coll->ctx, h->d_energies, 5, (void *)(on_b ? b : a))) {
+            set_error("slab step: the all-reduce of the energy sums failed");
+            return MSM_AMD_EHIP;
+        }
+        if (on_b) {
+            HIPCHK(hipEventRecord(h->ev_energy, b));
+            h->energy_on_b = true;
+        }
     }
     HIPCHK(hipGetLastError());
     return MSM_AMD_OK;
@@ -1703,6 +1737,7 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
 extern "C" int msm_amd_slab_energies(msm_amd_handle *h, const msm_amd_collectives *coll, double energies[MSM_AMD_U_COUNT]) {
     if (!h || !energies) return MSM_AMD_EINVAL;
     HIPCHK(hipSetDevice(h->device));
+    if (h->energy_on_b) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_energy, 0));
     HIPCHK(hipMemcpyAsync(h->h_energies, h->d_energies, 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     double sums[5];

@@ -133,8 +133,10 @@ void launch_cluster_sort(hipStream_t st, const double *d_r, const double *d_q, i
 void launch_pair_clusters(hipStream_t st, const ClusterGeom &g, const ClusterBuffers &b, const PairParams &pp, double *acc,
                           double *epart, int variant, int n_total, hipEvent_t *ev, int max_wgs = 0, hipEvent_t after_lists = nullptr,
                           int lds_pad = 0, // lds_pad: unused LDS bytes per workgroup of the list-walking kernel (caps the waves per SIMD)
-                          const std::function<void()> *between = nullptr); // called between the list build and the pair kernel: what it
-                                                                           // queues on st runs there
+                          const std::function<void()> *between = nullptr, // called between the list build and the pair kernel: what it
+                                                                          // queues on st runs there
+                          int nchunks = 1, // the list-walking kernel (one-wave workgroups) in that many launches
+                          const std::function<void()> *before_last = nullptr); // called before the last of several launches
 
 // ---- neighbour structures kept over several evaluations (msm_amd_eval_reuse) ----
 // The "pair set": the cluster order of the last rebuild, frozen (slots, original indices, fine-bin prefix sums), with

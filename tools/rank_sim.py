@@ -22,8 +22,14 @@ c_step = not (len(sys.argv) > 5 and sys.argv[5] == "py")
 side = None if os.environ.get("RANK_SIM_STREAM", "side") == "default" else torch.cuda.Stream()
 if side is not None:
     torch.cuda.set_stream(side)
-s = SlabRank(torch, FakeDist(), msm_amd, desc, r, q, RANK, W, 0, perturb=True, mode=mode,
-             collectives=NullCollectives(RANK, W) if W > 1 else None, c_step=c_step, stream=side)
+# RANK_SIM_DELAY="halo,gather,reduce" (microseconds): the collectives hold their stream that long instead of returning at once
+delay = [float(x) for x in os.environ.get("RANK_SIM_DELAY", "").split(",") if x]
+if W > 1 and delay:
+    from rank_sim_common import delay_collectives
+    coll = delay_collectives(torch, RANK, W, *delay)
+else:
+    coll = NullCollectives(RANK, W) if W > 1 else None
+s = SlabRank(torch, FakeDist(), msm_amd, desc, r, q, RANK, W, 0, perturb=True, mode=mode, collectives=coll, c_step=c_step, stream=side)
 for kv in filter(None, (sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else "").split(",")):   # engine options: key=value,key=value
     k, v = kv.split("=")
     s.eng.set_option(k, int(v))
