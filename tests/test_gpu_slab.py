@@ -508,7 +508,7 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["MSM_AMD_BENCH_BACKEND"] = "gloo"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--particles", "40000", "--steps", "2",
-                        "--warmup", "1", "--no-cpu-baseline", "--no-accuracy"], env=env, capture_output=True, text=True, timeout=300)
+                        "--warmup", "1", "--spinup-steps", "2", "--no-cpu-baseline", "--no-accuracy"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
