@@ -184,7 +184,8 @@ def main():
 
     # evaluations are queued back to back on every rank too: the reduced sums stay on the device until they are read
     run_step = stepper.step if world == 1 else (lambda: stepper.step(want_energies=False))
-    for _ in range(max(0, args.spinup_steps)):
+    spinup = max(0, args.spinup_steps) * world   # (a rank's step is shorter: the same time under load on every rank count)
+    for _ in range(spinup):
         run_step()
     for _ in range(args.warmup):
         run_step()
@@ -256,7 +257,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "spinup_steps": max(0, args.spinup_steps),
+            "spinup_steps": spinup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
             "scaling": "strong",
