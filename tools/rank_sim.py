@@ -33,11 +33,16 @@ s = SlabRank(torch, FakeDist(), msm_amd, desc, r, q, RANK, W, 0, perturb=True, m
 for kv in filter(None, (sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else "").split(",")):   # engine options: key=value,key=value
     k, v = kv.split("=")
     s.eng.set_option(k, int(v))
-for _ in range(3): s.step(want_energies=False)
-torch.cuda.synchronize()
+# 0.1 s of the same steps first: the GPU takes about 30 ms of load to reach its clocks (a rank of 8 timed over 20 steps
+# behind 3 warm-up steps never left that ramp)
 t0 = time.perf_counter()
-for _ in range(20): s.step(want_energies=False)
+while time.perf_counter() - t0 < 0.1:
+    for _ in range(10): s.step(want_energies=False)
+    torch.cuda.synchronize()
+NT = 100
+t0 = time.perf_counter()
+for _ in range(NT): s.step(want_energies=False)
 torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / 20
+dt = (time.perf_counter() - t0) / NT
 prof = SlabProfiler(torch, s).profile(5)
 print("N", N, "M", list(desc.M), "W", W, "rank", RANK, "p", p, "mode", s.eng.slab_exchange_mode(W, mode) if W > 1 else "-", "c_step", s.coll is not None, "n_own", s.n_own, "n_tot", s.n_tot, "ms/step", round(dt * 1e3, 3), {k: round(v, 3) for k, v in prof.items()})
