@@ -146,8 +146,8 @@ struct msm_amd_handle {
                               // 8 / 4 / 2 ranks of 1M particles); 3 and the level-0 convolution and the last prolongation, i.e.
                               // the whole grid stage (a further -21 us at 8 ranks, nothing at 4, +35 us at 2, where a
                               // convolution of 54 planes competes with the pair kernel; 10M particles, 8 ranks: -1 %);
-                              // 4 and the anterpolation (slower everywhere); -1: 3 for a rank that owns at most 150 000
-                              // nodes of level 0 (12 planes of 96 x 96; with 32 planes of 256 x 256 the kernels of the grid
+                              // 4 and the anterpolation (slower everywhere); -1: 3 for a rank that owns at most 300 000
+                              // nodes of level 0 (12 or 24 planes of 96 x 96; with 32 planes of 256 x 256 the kernels of the grid
                               // stage fill the chip by themselves and 3 costs 3 %), else 2
     // parts of the grid branch on a second stream beside the pair branch: 1 all of it (slower: the level-0 convolution
     // wants the FP64 pipe the pair kernel is using), 2 the anterpolation (bound by the LDS port: -22 us), 3 and the chain
@@ -1583,7 +1583,7 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
     // need nothing from the other ranks.  What else follows the exchange on the second stream is opt_slab_overlap's:
     // small, latency-bound kernels pay there (the chain of the coarser levels; on a thin slab the whole grid stage),
     // large ones compete with the pair kernel for the FP64 pipe and do not.
-    const int ov = h->opt_slab_overlap >= 0 ? h->opt_slab_overlap : ((long)d.nzplanes * d.M[0] * d.M[1] <= 150000 ? 3 : 2);
+    const int ov = h->opt_slab_overlap >= 0 ? h->opt_slab_overlap : ((long)d.nzplanes * d.M[0] * d.M[1] <= 300000 ? 3 : 2);
     const bool two = ov != 0 && slab;
     if (two && (rc = ensure_stream_b(h))) return rc;
     h->pk_recorded = false;
