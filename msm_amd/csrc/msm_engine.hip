@@ -122,6 +122,7 @@ struct msm_amd_handle {
     int opt_pair_chunks = 2;  // launches of the list-walking pair kernel of a slab step whose last launch waits for the second stream
                               // (the earlier ones run while the exchanges travel; 1: one launch)
     hipEvent_t ev_restricted = nullptr;  // set for one grid stage: recorded behind its restrictions
+    hipEvent_t ev_stage_tail = nullptr;  // set for one whole grid stage: signalled by its last kernel (cleared when that happened)
     int opt_conv_sym = 2;       // tiled convolution: mirror columns of a stencil share their multiplications (2: and 16 outputs per thread; 0: off)
     int opt_transfer_chain = 1; // two prolongations per launch where the grids allow it
     int opt_conv_tile_planes = 0; // slab ranks: planes per tile of k_conv_split (0: chosen per launch)
@@ -139,6 +140,7 @@ struct msm_amd_handle {
     int pair_wgs_now = 0;     // A/B: cap on the workgroups of the pair kernel (0: one workgroup per four clusters; measured
                               // slower at 2, 3 and 4 workgroups per CU, and kernels of a second stream gain nothing from the room)
     int opt_slab_own_stream = 1; // slab step of a handle on the default stream: on streams of its own (0: as given, A/B)
+    int opt_tail_events = 1;   // slab step: events signalled by the completion of a stage's last kernel instead of a marker behind it (0: A/B)
     int opt_conv_leads = 1;    // slab step with the grid stage on the second stream: the pair kernel starts behind the restrictions (0: A/B)
     int opt_slab_overlap = -1; // slab step, what runs on a second stream beside the list build and the pair sum: 0 nothing (one
                               // stream: for several processes sharing one GPU, where cross-stream waits were seen to stall);
@@ -658,6 +660,7 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "slab_own_stream")) { h->opt_slab_own_stream = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "energy_on_b")) { h->opt_energy_on_b = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "pair_chunks")) { if (value >= 1 && value <= 8) { h->opt_pair_chunks = value; return MSM_AMD_OK; } }
+    if (!strcmp(key, "tail_events")) { h->opt_tail_events = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "conv_leads")) { h->opt_conv_leads = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "slab_overlap")) { h->opt_slab_overlap = value; return MSM_AMD_OK; }
     if (!strcmp(key, "conv_split")) { // shares of a level-0 tile's taps: conv_part holds the partial sums of shares 1..4
@@ -1091,9 +1094,15 @@ static int grid_stage(msm_amd_handle *h, bool front_done, int part = 0) {
         HIPCHK(hipStreamWaitEvent(h->stream_b, h->ev_gfork, 0));
         h->stream = h->stream_b; // the helpers below enqueue on the handle's stream
     }
-    for (int l = front_done ? 1 : 0; l + 1 < L; l++) restrict_level(h, l, h->gq[l], h->gq[l + 1]);
+    for (int l = front_done ? 1 : 0; l + 1 < L; l++) {
+        // (the event behind the restrictions is signalled by the last of them itself where that is a tiled kernel)
+        if (l + 2 == L && h->ev_restricted && h->opt_tail_events) msm::tail_event = h->ev_restricted;
+        restrict_level(h, l, h->gq[l], h->gq[l + 1]);
+    }
     if (h->ev_restricted) {
-        hipError_t e = hipEventRecord(h->ev_restricted, h->stream);
+        const bool signalled = h->opt_tail_events && msm::tail_event == nullptr && L - (front_done ? 1 : 0) >= 2;
+        msm::tail_event = nullptr;
+        hipError_t e = signalled ? hipSuccess : hipEventRecord(h->ev_restricted, h->stream);
         h->ev_restricted = nullptr;
         if (e != hipSuccess) { set_error("hipEventRecord failed: %s", hipGetErrorString(e)); return MSM_AMD_EHIP; }
     }
@@ -1120,9 +1129,13 @@ static int grid_stage(msm_amd_handle *h, bool front_done, int part = 0) {
         mark(h, T_PRO);
     }
     if (L >= 2) {
+        // (an event behind the stage is signalled by this kernel itself where it is the tiled one)
+        if (h->ev_stage_tail && h->opt_tail_events) msm::tail_event = h->ev_stage_tail;
         // a slab rank reads the potentials of its own planes and p/2 planes either side only
         if (slab && d.nzplanes + p < d.M[2]) prolong_level_add(h, 0, h->ge[1], h->ge[0], d.zplane0 - p / 2, d.nzplanes + p);
         else prolong_level_add(h, 0, h->ge[1], h->ge[0]);
+        if (h->ev_stage_tail && h->opt_tail_events && msm::tail_event == nullptr) h->ev_stage_tail = nullptr; // taken
+        msm::tail_event = nullptr;
     }
     HIPCHK(hipGetLastError());
     return MSM_AMD_OK;
@@ -1624,9 +1637,13 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
     const bool conv_first = two && ov == 5 && d.L >= 2 && !h->profiling;
     const bool grid_on_b = two && (ov == 3 || ov == 4) && !h->profiling, anterp_on_b = grid_on_b && ov == 4;
     if ((rc = msm_amd_stage_bin(h, d_r, d_q))) return rc;
-    if (!anterp_on_b && (rc = msm_amd_stage_anterpolate(h))) return rc;
+    // (the fork event is signalled by the last kernel of the anterpolation itself when that is the stage in front of it)
+    if (two && !anterp_on_b && h->opt_tail_events) msm::tail_event = h->ev_fork;
+    if (!anterp_on_b && (rc = msm_amd_stage_anterpolate(h))) { msm::tail_event = nullptr; return rc; }
     if (two) {
-        HIPCHK(hipEventRecord(h->ev_fork, a));
+        const bool signalled = !anterp_on_b && h->opt_tail_events && msm::tail_event == nullptr;
+        msm::tail_event = nullptr;
+        if (!signalled) HIPCHK(hipEventRecord(h->ev_fork, a));
         HIPCHK(hipStreamWaitEvent(b, h->ev_fork, 0));
     }
     if (slab) {
@@ -1678,12 +1695,15 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
         // restrictions in front of the convolution - as a rule they have long finished beside the list build.
         const bool conv_leads = grid_on_b && h->opt_conv_leads && d.L >= 2;
         if (conv_leads) h->ev_restricted = h->ev_pairs;
+        if (grid_on_b) h->ev_stage_tail = h->ev_join;
         if (!rc && grid_on_b) rc = grid_stage(h, xmode == MSM_AMD_SLAB_HALO, 0);
+        const bool join_signalled = grid_on_b && !rc && h->ev_stage_tail == nullptr;
+        h->ev_stage_tail = nullptr;
         const bool lead_recorded = conv_leads && !rc && h->ev_restricted == nullptr;
         h->ev_restricted = nullptr;
         if (lead_recorded) wait_before_pairs = true;
-        else if (!rc && coarse_on_b) rc = grid_stage(h, xmode == MSM_AMD_SLAB_HALO, 1);
-        if (!rc && two && hipEventRecord(h->ev_join, b) != hipSuccess) { set_error("slab step: hipEventRecord failed"); rc = MSM_AMD_EHIP; }
+        if (!rc && coarse_on_b) rc = grid_stage(h, xmode == MSM_AMD_SLAB_HALO, 1);
+        if (!rc && two && !join_signalled && hipEventRecord(h->ev_join, b) != hipSuccess) { set_error("slab step: hipEventRecord failed"); rc = MSM_AMD_EHIP; }
         h->stream = a;
         if (rc) return rc;
     }
@@ -1710,7 +1730,12 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
     if (two) HIPCHK(hipStreamWaitEvent(a, h->ev_join, 0));
     if (!(slab && grid_on_b) && (rc = grid_stage(h, slab && xmode == MSM_AMD_SLAB_HALO, conv_first ? 4 : coarse_on_b ? 2 : 0))) return rc;
     if ((rc = msm_amd_stage_interpolate(h, d_acc))) return rc;
-    if ((rc = queue_energies(h, true))) return rc;
+    const bool energy_b = coll && world > 1 && two && h->opt_energy_on_b;
+    if (energy_b && h->opt_tail_events) msm::tail_event = h->ev_fork; // (signalled by the kernel that writes the sums)
+    rc = queue_energies(h, true);
+    const bool sums_signalled = energy_b && h->opt_tail_events && msm::tail_event == nullptr;
+    msm::tail_event = nullptr;
+    if (rc) return rc;
     // The five sums are added over the ranks on the second stream when the step has one: nothing of the next step waits
     // for them (its own sums are written behind its join with the second stream, which works through its queue in
     // order), only msm_amd_slab_energies does.
@@ -1718,7 +1743,7 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
     if (coll && world > 1) {
         const bool on_b = two && h->opt_energy_on_b;
         if (on_b) {
-            HIPCHK(hipEventRecord(h->ev_fork, a));
+            if (!sums_signalled) HIPCHK(hipEventRecord(h->ev_fork, a));
             HIPCHK(hipStreamWaitEvent(b, h->ev_fork, 0));
         }
         if (coll->all_reduce_sum(coll->ctx, h->d_energies, 5, (void *)(on_b ? b : a))) {

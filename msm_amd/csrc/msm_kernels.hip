@@ -17,6 +17,8 @@
 
 namespace msm {
 
+thread_local hipEvent_t tail_event = nullptr;
+
 // ---------------------------------------------------------------------------
 // binning
 // ---------------------------------------------------------------------------
@@ -1210,8 +1212,8 @@ void launch_prolong_tiled_add(hipStream_t st, const double *coarse, double *fine
     Transfer3 t = make_transfer(Mf, p, J);
     t.z0 = z0; t.nz = nz; // fine planes [z0, z0 + nz) modulo Mf[2]
     const int nb = ((t.Mf[0] + PR_T - 1) / PR_T) * ((t.Mf[1] + PR_T - 1) / PR_T) * ((nz + PR_T - 1) / PR_T);
-    if (p == 4) hipLaunchKernelGGL((k_prolong_tiled<2>), dim3(nb), dim3(PR_THREADS), 0, st, coarse, fine, t);
-    else hipLaunchKernelGGL((k_prolong_tiled<3>), dim3(nb), dim3(PR_THREADS), 0, st, coarse, fine, t);
+    if (p == 4) MSM_LAUNCH_TAIL((k_prolong_tiled<2>), dim3(nb), dim3(PR_THREADS), 0, st, coarse, fine, t);
+    else MSM_LAUNCH_TAIL((k_prolong_tiled<3>), dim3(nb), dim3(PR_THREADS), 0, st, coarse, fine, t);
 }
 
 void launch_restrict_tiled(hipStream_t st, const double *fine, double *coarse, const int Mf[3], int p, const double J[4], int z0,
@@ -1219,8 +1221,8 @@ void launch_restrict_tiled(hipStream_t st, const double *fine, double *coarse, c
     Transfer3 t = make_transfer(Mf, p, J);
     t.z0 = z0; t.nz = nz; // coarse planes [z0, z0 + nz) modulo Mc[2]
     const int nb = ((t.Mc[0] + TR_T - 1) / TR_T) * ((t.Mc[1] + TR_T - 1) / TR_T) * ((nz + TR_T - 1) / TR_T);
-    if (p == 4) hipLaunchKernelGGL((k_restrict_tiled<2>), dim3(nb), dim3(TR_THREADS), 0, st, fine, coarse, t);
-    else hipLaunchKernelGGL((k_restrict_tiled<3>), dim3(nb), dim3(TR_THREADS), 0, st, fine, coarse, t);
+    if (p == 4) MSM_LAUNCH_TAIL((k_restrict_tiled<2>), dim3(nb), dim3(TR_THREADS), 0, st, fine, coarse, t);
+    else MSM_LAUNCH_TAIL((k_restrict_tiled<3>), dim3(nb), dim3(TR_THREADS), 0, st, fine, coarse, t);
 }
 // ---------------------------------------------------------------------------
 // grid convolution
@@ -2318,7 +2320,7 @@ void launch_energy_all(hipStream_t st, const EnergyPartialsArgs &a, int nparts, 
     hipLaunchKernelGGL(k_energy_all, dim3(nparts, 4), dim3(256), 0, st, a, in, raw ? 1 : 0, out, out_second, ticket);
 }
 void launch_raw_sums(hipStream_t st, const EnergyInputs &in, double *out5) {
-    hipLaunchKernelGGL(k_raw_sums, dim3(1), dim3(256), 0, st, in, out5);
+    MSM_LAUNCH_TAIL(k_raw_sums, dim3(1), dim3(256), 0, st, in, out5);
 }
 void launch_finalize_energies(hipStream_t st, const EnergyInputs &in, double *out7, double *out7_second) {
     hipLaunchKernelGGL(k_finalize_energies, dim3(1), dim3(256), 0, st, in, out7, out7_second);

@@ -2,8 +2,26 @@
 #pragma once
 #include <functional>
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 namespace msm {
+
+// The last kernel of a stage can signal an event by its own completion (hipExtLaunchKernelGGL's stop event) instead of
+// through a marker queued behind it with hipEventRecord, which keeps the next kernel of the same stream waiting for some
+// microseconds.  The engine sets tail_event before the stage; the launch that goes through MSM_LAUNCH_TAIL takes it.  A
+// stage that took another path leaves it set, and the engine records the event the ordinary way.
+extern thread_local hipEvent_t tail_event;
+inline hipEvent_t take_tail_event() {
+    hipEvent_t e = tail_event;
+    tail_event = nullptr;
+    return e;
+}
+#define MSM_LAUNCH_TAIL(kernel, grid, block, lds, st, ...)                                                  \
+    do {                                                                                                   \
+        hipEvent_t tail_e_ = msm::take_tail_event();                                                       \
+        if (tail_e_) hipExtLaunchKernelGGL(kernel, grid, block, lds, st, nullptr, tail_e_, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                \
+    } while (0)
 
 // Uniform binning of the periodic cell.  A particle with fractional coordinate
 // s in [0,1) falls into bin min(int(s*nb), nb-1) per axis (x fastest); the

@@ -578,8 +578,8 @@ bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &s
             const int rec = (2 + sp.p + 1 + 1) / 2 * 2;
             const size_t dyn = sizeof(double) * ((size_t)(R * R * R + 1) / 2 * 2 + (size_t)nw * 64 * rec);
             hipLaunchKernelGGL(k, dim3(ntl), dim3(64 * nw), dyn, st, S, sp, tl, scratch, tile_used);
-            if (sp.p == 4) hipLaunchKernelGGL((k_anterp_combine<4>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
-            else hipLaunchKernelGGL((k_anterp_combine<6>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
+            if (sp.p == 4) MSM_LAUNCH_TAIL((k_anterp_combine<4>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
+            else MSM_LAUNCH_TAIL((k_anterp_combine<6>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
             return true;
         }
         (void)hipGetLastError();
@@ -593,7 +593,7 @@ bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &s
         }
         attr4 = true;
         hipLaunchKernelGGL(kern, dim3(ntl), dim3(256), bytes, st, S, sp, tl, scratch, tile_used);
-        hipLaunchKernelGGL((k_anterp_combine<4>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
+        MSM_LAUNCH_TAIL((k_anterp_combine<4>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
     } else {
         const size_t bytes = 4 * sizeof(double) * (AT + 5) * (AT + 5) * (AT + 5);
         auto kern = k_anterp_tiles<6>;
@@ -603,7 +603,7 @@ bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &s
         }
         attr6 = true;
         hipLaunchKernelGGL(kern, dim3(ntl), dim3(256), bytes, st, S, sp, tl, scratch, tile_used);
-        hipLaunchKernelGGL((k_anterp_combine<6>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
+        MSM_LAUNCH_TAIL((k_anterp_combine<6>), dim3(gb), dim3(256), 0, st, scratch, tile_used, sp, tl, grid);
     }
     return true;
 }
