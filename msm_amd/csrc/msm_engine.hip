@@ -119,6 +119,7 @@ struct msm_amd_handle {
     hipEvent_t pairs_after = nullptr; // set for one msm_amd_stage_pairs call: recorded between the list build and the pair kernel
     std::function<void()> pairs_between; // set for one msm_amd_stage_pairs call: called between the list build and the pair kernel
     std::function<void()> pairs_before_last; // the same, before the last launch of a pair kernel launched in chunks
+    int pairs_chunks_now = 1;                // launches of the list-walking pair kernel of the msm_amd_stage_pairs call under way
     int opt_pair_chunks = 2;  // launches of the list-walking pair kernel of a slab step whose last launch waits for the second stream
                               // (the earlier ones run while the exchanges travel; 1: one launch)
     hipEvent_t ev_restricted = nullptr;  // set for one grid stage: recorded behind its restrictions
@@ -141,6 +142,8 @@ struct msm_amd_handle {
                               // slower at 2, 3 and 4 workgroups per CU, and kernels of a second stream gain nothing from the room)
     int opt_slab_own_stream = 1; // slab step of a handle on the default stream: on streams of its own (0: as given, A/B)
     int opt_tail_events = 1;   // slab step: events signalled by the completion of a stage's last kernel instead of a marker behind it (0: A/B)
+    int opt_pair_chunks_coarse = -1; // the same where only the chain of the coarser levels runs beside the pair kernel and nothing
+                                     // waits (-1: four for a rank with more than a million level-0 nodes, else one)
     int opt_conv_leads = 1;    // slab step with the grid stage on the second stream: the pair kernel starts behind the restrictions (0: A/B)
     int opt_slab_overlap = -1; // slab step, what runs on a second stream beside the list build and the pair sum: 0 nothing (one
                               // stream: for several processes sharing one GPU, where cross-stream waits were seen to stall);
@@ -661,6 +664,7 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "energy_on_b")) { h->opt_energy_on_b = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "pair_chunks")) { if (value >= 1 && value <= 8) { h->opt_pair_chunks = value; return MSM_AMD_OK; } }
     if (!strcmp(key, "tail_events")) { h->opt_tail_events = value != 0; return MSM_AMD_OK; }
+    if (!strcmp(key, "pair_chunks_coarse")) { if (value >= -1 && value <= 8) { h->opt_pair_chunks_coarse = value; return MSM_AMD_OK; } }
     if (!strcmp(key, "conv_leads")) { h->opt_conv_leads = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "slab_overlap")) { h->opt_slab_overlap = value; return MSM_AMD_OK; }
     if (!strcmp(key, "conv_split")) { // shares of a level-0 tile's taps: conv_part holds the partial sums of shares 1..4
@@ -751,7 +755,7 @@ extern "C" int msm_amd_stage_pairs(msm_amd_handle *h, double *d_acc) {
         cb.acc_slots = h->fused_acc ? h->acc_slots : nullptr;
         launch_pair_clusters(h->stream, h->clg, cb, h->pp, d_acc, h->epart, h->opt_pair_variant - 5, h->N,
                              h->profiling ? h->ev_pk : nullptr, h->pair_wgs_now, h->pairs_after, h->opt_pair_lds_pad | (h->opt_pair_wpb << 20) | (h->opt_list_wpb << 24),
-                             h->pairs_between ? &h->pairs_between : nullptr, h->pairs_before_last ? h->opt_pair_chunks : 1,
+                             h->pairs_between ? &h->pairs_between : nullptr, h->pairs_chunks_now,
                              h->pairs_before_last ? &h->pairs_before_last : nullptr);
         h->pairs_after = nullptr;
         h->pairs_between = nullptr;
@@ -1723,7 +1727,15 @@ extern "C" int msm_amd_slab_step(msm_amd_handle *h, const msm_amd_collectives *c
             conv_rc = grid_stage(h, halo, 3);
         };
     }
+    // in several launches also where nothing waits: between them the chain of the coarser levels on the second stream gets
+    // the wave slots it does not get while one launch has workgroups left to start, and is done when the pair kernel is
+    // (the chain of a 256^3 grid is worth four launches - a rank of 8 at 10M particles: 2.98 -> 2.87 ms - that of a 96^3 grid
+    // costs more at the boundaries than it gains)
+    const int chunks_coarse = h->opt_pair_chunks_coarse >= 0 ? h->opt_pair_chunks_coarse
+                                                             : ((long)d.nzplanes * d.M[0] * d.M[1] > 1000000 ? 4 : 1);
+    h->pairs_chunks_now = wait_before_pairs ? h->opt_pair_chunks : (coarse_on_b ? std::max(1, chunks_coarse) : 1);
     rc = msm_amd_stage_pairs(h, d_acc);
+    h->pairs_chunks_now = 1;
     h->pairs_between = nullptr;
     h->pairs_before_last = nullptr;
     if (rc || (rc = conv_rc)) return rc;

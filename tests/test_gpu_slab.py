@@ -408,7 +408,8 @@ def test_slab_step_options_keep_the_bits(rank):
              {"conv_tile_planes": 6}, {"conv_tile_planes": 8}, {"conv_tile_planes": 9},
              {"conv_tile_planes": 10}, {"conv_tile_planes": 12, "slab_overlap": 1}, {"pair_wpb": 2}, {"pair_wpb": 4},
              {"list_wpb": 1}, {"pair_lds_pad": 17408}, {"acc_slots": 0}, {"energy_fused": 1},
-             {"conv_leads": 0}, {"pair_chunks": 1}, {"pair_chunks": 3}, {"energy_on_b": 0}, {"tail_events": 0}]
+             {"conv_leads": 0}, {"pair_chunks": 1}, {"pair_chunks": 3}, {"energy_on_b": 0}, {"tail_events": 0},
+             {"slab_overlap": 2, "pair_chunks_coarse": 4}, {"slab_overlap": 2, "pair_chunks_coarse": 1}]
     # (face_cut 0 changes the clusters, hence the order of the sums: compared to rounding below)
     for opts in cases:
         acc, sums = _one_rank_steps(rank, world, opts)
