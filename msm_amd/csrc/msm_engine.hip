@@ -653,6 +653,7 @@ extern "C" int msm_amd_set_option(msm_amd_handle *h, const char *key, int value)
     if (!strcmp(key, "conv_groups")) { h->opt_conv_groups = value; return MSM_AMD_OK; } // 2: for whole grids too (A/B)
     if (!strcmp(key, "interp_remap")) { h->sopt.interp_remap = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "interp_split")) { if (value >= 0 && value <= 16) { h->sopt.interp_split = value; return MSM_AMD_OK; } }
+    if (!strcmp(key, "anterp_cols_weights")) { h->sopt.anterp_cols_weights = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "anterp_cols_waves")) { if (value == 0 || value == 4 || value == 8 || value == 16) { h->sopt.anterp_cols_waves = value; return MSM_AMD_OK; } }
     if (!strcmp(key, "anterp_cols_order4")) { h->sopt.anterp_cols_order4 = value != 0; return MSM_AMD_OK; }
     if (!strcmp(key, "anterp_cols")) { h->sopt.anterp_cols = value != 0; return MSM_AMD_OK; }

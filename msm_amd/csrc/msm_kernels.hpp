@@ -210,6 +210,7 @@ struct SplineOpts {
     int anterp_cols_waves = 0;      // waves per tile workgroup of the column kernel: 4, 8, 16, or 0 = by the share of owned planes
     bool anterp_cols_order4 = false; // the column kernel at order 4 too
     bool anterp_cols = true;        // register accumulation per column (cluster order, columns up to 2 x 2 cells)
+    bool anterp_cols_weights = true; // order 6: the staged records hold the particles' weights, not their offsets (same bits)
 };
 bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &sp, const TileGeom &tl, double *scratch,
                          int *tile_used, double *grid, const SplineOpts &opt);

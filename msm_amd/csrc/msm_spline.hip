@@ -187,7 +187,13 @@ __global__ __launch_bounds__(256) void k_anterp_tiles(TileSrc S, SplineParams sp
 // consecutive sums starting at cz; dx and dy only select which polynomial piece a lane evaluates (zero outside
 // the particle's support), and the walk visits the z cells in turn so that the register indices are fixed at
 // compile time.  The LDS block is touched once per column instead of P times per particle.
-template <int P, int KX, int KY>
+// WTS: the staged record of a particle holds its weights themselves - the P z weights times the charge, and the x and y
+// weights of all FX and FY nodes of the column's footprint (zero outside the particle's support) - instead of the
+// offsets from which every lane evaluated its own two polynomial pieces: the lane that stages a particle evaluates the
+// 3 P pieces once, a lane of the walk reads "its" x and y weight (two 8-byte reads, 7 distinct addresses each) and is left
+// with one multiplication and P additions per particle.  Same arithmetic, same bits; a third of the vector
+// instructions and four fifths of the LDS bytes per particle.  Records are twice as long, so a batch is 32 particles.
+template <int P, int KX, int KY, bool WTS = false>
 __global__ __launch_bounds__(1024) void k_anterp_cols(TileSrc S, SplineParams sp, TileGeom tl, double *__restrict__ scratch,
                                                      int *__restrict__ tile_used) {
     constexpr int R = AT + P - 1, R3 = R * R * R, FX = KX + P - 1, FY = KY + P - 1;
@@ -222,8 +228,11 @@ __global__ __launch_bounds__(1024) void k_anterp_cols(TileSrc S, SplineParams sp
     if (!any_particle) return;
     for (int t = threadIdx.x; t < R3; t += blockDim.x) lds[t] = 0.0;
     __syncthreads();
-    constexpr int REC = ((2 + P + 1) + 1) / 2 * 2; // doubles per staged particle record (even: 16-byte reads)
-    double *__restrict__ stage = lds + ((R3 + 1) / 2 * 2) + wave * (64 * REC);
+    // doubles per staged particle record (even: 16-byte reads); a wave's staging area holds 64 records of offsets or 32 of weights
+    constexpr int REC = WTS ? ((P + FX + FY) + 1) / 2 * 2 : ((2 + P + 1) + 1) / 2 * 2;
+    constexpr int STAGE = WTS ? 32 * REC : 64 * REC;
+    static_assert(STAGE <= 64 * 10, "the launcher reserves 640 doubles per wave");
+    double *__restrict__ stage = lds + ((R3 + 1) / 2 * 2) + wave * 640;
     const int a = lane % FX, b = lane / FX;
     const bool active = lane < FX * FY;
     double cx[KX][P], cy[KY][P];
@@ -268,6 +277,60 @@ __global__ __launch_bounds__(1024) void k_anterp_cols(TileSrc S, SplineParams sp
             // sort put the particle in
             const int dx = min(max((int)ux - colx * KX, 0), KX - 1), dy = min(max((int)uy - coly * KY, 0), KY - 1);
             const double lfx = ux - (double)(colx * KX + dx), lfy = uy - (double)(coly * KY + dy), lfz = uz - (double)(z0 + cz);
+            if constexpr (WTS) {
+                const int ai = min(a, FX - 1), bi = min(b, FY - 1); // (lanes beyond the footprint read a valid word, unused)
+                for (int half = 0; half < 2 && 32 * half < cnt; half++) {
+                    __builtin_amdgcn_wave_barrier();
+                    if ((lane >> 5) == half) {
+                        double *rec_mine = stage + (lane & 31) * REC;
+                        // the spline is even: node P-1-n at offset f weighs what node n weighs at 1 - f
+                        double vx[P], vy[P];
+                        const double lgz = 1.0 - lfz;
+#pragma unroll
+                        for (int n = 0; n < P / 2; n++) {
+                            rec_mine[n] = ptl.w * piece_eval<P>(sp.piece[n], lfz);
+                            rec_mine[P - 1 - n] = ptl.w * piece_eval<P>(sp.piece[n], lgz);
+                        }
+#pragma unroll
+                        for (int n = 0; n < P; n++) {
+                            // (exactly the pieces the other variant evaluates: piece n at the offset itself)
+                            vx[n] = piece_eval<P>(sp.piece[n], lfx);
+                            vy[n] = piece_eval<P>(sp.piece[n], lfy);
+                        }
+#pragma unroll
+                        for (int q = 0; q < FX; q++) {
+                            double v = 0.0;
+#pragma unroll
+                            for (int d = 0; d < KX; d++)
+                                if (q - d >= 0 && q - d < P) v = dx == d ? vx[q - d] : v;
+                            rec_mine[P + q] = v;
+                        }
+#pragma unroll
+                        for (int q = 0; q < FY; q++) {
+                            double v = 0.0;
+#pragma unroll
+                            for (int d = 0; d < KY; d++)
+                                if (q - d >= 0 && q - d < P) v = dy == d ? vy[q - d] : v;
+                            rec_mine[P + FX + q] = v;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int c = 0; c < AT; c++) {
+                        const int k0 = max(max(bnd[c], sb) - sb, 32 * half), k1 = min(min(bnd[c + 1], sb + cnt) - sb, 32 * half + 32);
+                        for (int k = k0; k < k1; k++) {
+                            const double *rec = stage + (k - 32 * half) * REC;
+                            double wz[P];
+#pragma unroll
+                            for (int cc = 0; cc < P; cc++) wz[cc] = rec[cc];
+                            const double wxy = rec[P + ai] * rec[P + FX + bi];
+#pragma unroll
+                            for (int cc = 0; cc < P; cc++) acc[c + cc] = fma(wxy, wz[cc], acc[c + cc]);
+                        }
+                    }
+                }
+                continue;
+            }
             // Every lane leaves what the others need of its particle (offsets inside the cell, the P z weights times
             // the charge, the cell inside the column) in the wave's staging area; the walk below reads one record per
             // particle with all lanes on the same address (broadcast reads), which costs far fewer instructions than
@@ -565,11 +628,16 @@ bool launch_anterp_tiled(hipStream_t st, const TileSrc &S, const SplineParams &s
         static bool attr[2][2][2] = {};
         const void *kern = nullptr;
         void (*k)(TileSrc, SplineParams, TileGeom, double *, int *) = nullptr;
+        const bool wts = opt.anterp_cols_weights && sp.p == 6;
 #define PICK(P, KX, KY) if (sp.p == P && S.cg.kx == KX && S.cg.ky == KY) k = k_anterp_cols<P, KX, KY>;
         PICK(4, 1, 1) PICK(4, 1, 2) PICK(4, 2, 1) PICK(4, 2, 2) PICK(6, 1, 1) PICK(6, 1, 2) PICK(6, 2, 1) PICK(6, 2, 2)
 #undef PICK
+#define PICK(KX, KY) if (wts && S.cg.kx == KX && S.cg.ky == KY) k = k_anterp_cols<6, KX, KY, true>;
+        PICK(1, 1) PICK(1, 2) PICK(2, 1) PICK(2, 2)
+#undef PICK
         kern = (const void *)k;
-        bool &done = attr[sp.p == 6][S.cg.kx - 1][S.cg.ky - 1];
+        static bool attr_w[2][2] = {};
+        bool &done = wts ? attr_w[S.cg.kx - 1][S.cg.ky - 1] : attr[sp.p == 6][S.cg.kx - 1][S.cg.ky - 1];
         if (k && (done || hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess)) {
             done = true;
             // 4 waves per tile fill the chip when every tile has particles; a rank that owns a thin slab has few busy

@@ -1162,6 +1162,36 @@ def test_open_boundary_one_million(msm, torch):
     eng.close()
 
 
+@pytest.mark.parametrize("grid", [(96, 96, 96), (48, 64, 40)])
+def test_anterpolation_weight_records_keep_the_bits(msm, torch, grid):
+    """The column kernel of the anterpolation with the particles' weights in its staged records (default) and with their
+    offsets, from which every lane evaluates its own polynomial pieces: the same products in the same order, so the grid
+    charges, and with them everything downstream, agree bit for bit; a crowded region (long runs, many batches) and a
+    grid of unequal, non-cubic sizes included."""
+    N, A = 150000, (1.0, 1.0, 1.0)
+    r, q = O.neutral_system(N, A, seed=91)
+    rng = np.random.default_rng(5)
+    r[:8000] = (0.62 + 0.01 * rng.standard_normal((8000, 3))) % 1.0
+    lib = msm.load()
+    L, a = 3, 4.0 / max(grid)
+    hL = (2.0 ** (L - 1)) * A[0] / min(grid)
+    beta = lib.choosebetaNew(1e-12, (2.0 ** L) * a, hL)
+    kmax = int(np.ceil(lib.choosekmax(1e-12, beta, hL)))
+    desc = msm.plan_explicit(N, A, grid, 6, 10, L, a, beta, kmax)
+    eng = msm.Engine(desc)
+    rd, qd = torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0")
+    en1, acc1 = eng.eval(rd, qd)
+    acc1 = acc1.clone()
+    q1 = eng.grid_tensor(0, 0).clone()
+    eng.set_option("anterp_cols_weights", 0)
+    en0, acc0 = eng.eval(rd, qd)
+    q0 = eng.grid_tensor(0, 0).clone()
+    assert float(q1.abs().max()) > 0
+    assert torch.equal(q0, q1)
+    assert np.array_equal(en0, en1) and torch.equal(acc0, acc1)
+    eng.close()
+
+
 @pytest.mark.parametrize("p,conv", [(6, 0), (4, 2)])
 def test_slot_order_accelerations_keep_the_bits(msm, torch, p, conv):
     """A whole evaluation hands the short-range accelerations from the pair kernels to the interpolation kernel in slot
