@@ -279,40 +279,49 @@ __global__ __launch_bounds__(1024) void k_anterp_cols(TileSrc S, SplineParams sp
             const double lfx = ux - (double)(colx * KX + dx), lfy = uy - (double)(coly * KY + dy), lfz = uz - (double)(z0 + cz);
             if constexpr (WTS) {
                 const int ai = min(a, FX - 1), bi = min(b, FY - 1); // (lanes beyond the footprint read a valid word, unused)
+                // every lane evaluates the weights of its own particle once (registers); the two halves of the wave then
+                // stage their records one after the other
+                double rw[REC];
+                {
+                    // the spline is even: node P-1-n at offset f weighs what node n weighs at 1 - f
+                    const double lgz = 1.0 - lfz;
+#pragma unroll
+                    for (int n = 0; n < P / 2; n++) {
+                        rw[n] = ptl.w * piece_eval<P>(sp.piece[n], lfz);
+                        rw[P - 1 - n] = ptl.w * piece_eval<P>(sp.piece[n], lgz);
+                    }
+                    double vx[P], vy[P];
+#pragma unroll
+                    for (int n = 0; n < P; n++) {
+                        // (exactly the pieces the other variant evaluates: piece n at the offset itself)
+                        vx[n] = piece_eval<P>(sp.piece[n], lfx);
+                        vy[n] = piece_eval<P>(sp.piece[n], lfy);
+                    }
+#pragma unroll
+                    for (int q = 0; q < FX; q++) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int d = 0; d < KX; d++)
+                            if (q - d >= 0 && q - d < P) v = dx == d ? vx[q - d] : v;
+                        rw[P + q] = v;
+                    }
+#pragma unroll
+                    for (int q = 0; q < FY; q++) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int d = 0; d < KY; d++)
+                            if (q - d >= 0 && q - d < P) v = dy == d ? vy[q - d] : v;
+                        rw[P + FX + q] = v;
+                    }
+#pragma unroll
+                    for (int q = P + FX + FY; q < REC; q++) rw[q] = 0.0;
+                }
                 for (int half = 0; half < 2 && 32 * half < cnt; half++) {
                     __builtin_amdgcn_wave_barrier();
                     if ((lane >> 5) == half) {
-                        double *rec_mine = stage + (lane & 31) * REC;
-                        // the spline is even: node P-1-n at offset f weighs what node n weighs at 1 - f
-                        double vx[P], vy[P];
-                        const double lgz = 1.0 - lfz;
+                        double2 *rec_mine = (double2 *)(stage + (lane & 31) * REC);
 #pragma unroll
-                        for (int n = 0; n < P / 2; n++) {
-                            rec_mine[n] = ptl.w * piece_eval<P>(sp.piece[n], lfz);
-                            rec_mine[P - 1 - n] = ptl.w * piece_eval<P>(sp.piece[n], lgz);
-                        }
-#pragma unroll
-                        for (int n = 0; n < P; n++) {
-                            // (exactly the pieces the other variant evaluates: piece n at the offset itself)
-                            vx[n] = piece_eval<P>(sp.piece[n], lfx);
-                            vy[n] = piece_eval<P>(sp.piece[n], lfy);
-                        }
-#pragma unroll
-                        for (int q = 0; q < FX; q++) {
-                            double v = 0.0;
-#pragma unroll
-                            for (int d = 0; d < KX; d++)
-                                if (q - d >= 0 && q - d < P) v = dx == d ? vx[q - d] : v;
-                            rec_mine[P + q] = v;
-                        }
-#pragma unroll
-                        for (int q = 0; q < FY; q++) {
-                            double v = 0.0;
-#pragma unroll
-                            for (int d = 0; d < KY; d++)
-                                if (q - d >= 0 && q - d < P) v = dy == d ? vy[q - d] : v;
-                            rec_mine[P + FX + q] = v;
-                        }
+                        for (int q = 0; q < REC / 2; q++) rec_mine[q] = make_double2(rw[2 * q], rw[2 * q + 1]);
                     }
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
