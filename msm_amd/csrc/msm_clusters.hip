@@ -408,25 +408,40 @@ __global__ __launch_bounds__(256) void k_cs_colsort(ClusterGeom g, ClusterBuffer
     if (col == 0 && threadIdx.x < CL_G) // one cluster of inert slots behind the last possible cluster (see k_cl_bbox)
         b.ps[(size_t)CL_G * g.max_clusters + threadIdx.x] = make_double4(g.far, g.far, g.far, 0.0);
     __syncthreads();
-    // bounding boxes of the column's clusters (the slots were written by this workgroup: visible after the barriers)
-    for (int k = threadIdx.x; k < ncl; k += 256) {
+    // bounding boxes of the column's clusters (the slots were written by this workgroup: visible after the barriers):
+    // eight lanes to a cluster, one slot each, so that a cluster's eight loads travel together; minima and maxima are
+    // exact, whatever the order they are taken in
+    for (int kb = 0; kb < ncl; kb += 256 / CL_G) {
+        const int k = kb + (int)threadIdx.x / CL_G, m = (int)threadIdx.x % CL_G;
         const int nin = g.nface ? CL_G : min(CL_G, n - CL_G * k); // (with padding inside the column: whoever is no padding)
-        const double4 *p = b.ps + (size_t)CL_G * (c0 + k);
-        double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
-        bool all_owned = true;
-        for (int m = 0; m < nin; m++) {
-            if (g.nface && b.order[(size_t)CL_G * (c0 + k) + m] == CL_DUMMY) continue;
-            const double4 v = p[m];
-            l[0] = fmin(l[0], v.x); h[0] = fmax(h[0], v.x);
-            l[1] = fmin(l[1], v.y); h[1] = fmax(h[1], v.y);
-            l[2] = fmin(l[2], v.z); h[2] = fmax(h[2], v.z);
-            if (g.n_owned != CL_ALL_OWNED) all_owned = all_owned && b.order[(size_t)CL_G * (c0 + k) + m] < g.n_owned;
+        const size_t slot = (size_t)CL_G * (c0 + k) + m;
+        bool in = k < ncl && m < nin, own = true;
+        if (in && (g.nface || g.n_owned != CL_ALL_OWNED)) {
+            const int o = b.order[slot];
+            if (g.nface && o == CL_DUMMY) in = false;
+            else if (g.n_owned != CL_ALL_OWNED) own = o < g.n_owned;
         }
-        const int kk = c0 + k;
-        b.blo[kk] = make_double4(l[0], l[1], l[2], 0.0);
-        b.bhi[kk] = make_double4(h[0], h[1], h[2], 0.0);
-        b.fbox[2 * (size_t)kk] = make_float4(__double2float_rd(l[0]), __double2float_rd(l[1]), __double2float_rd(l[2]), all_owned ? 1.f : 0.f);
-        b.fbox[2 * (size_t)kk + 1] = make_float4(__double2float_ru(h[0]), __double2float_ru(h[1]), __double2float_ru(h[2]), 0.f);
+        double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+        if (in) {
+            const double4 v = b.ps[slot];
+            l[0] = h[0] = v.x; l[1] = h[1] = v.y; l[2] = h[2] = v.z;
+        }
+#pragma unroll
+        for (int off = 1; off < CL_G; off <<= 1)
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                l[d] = fmin(l[d], __shfl_xor(l[d], off));
+                h[d] = fmax(h[d], __shfl_xor(h[d], off));
+            }
+        const unsigned long long owned = __ballot(own);
+        const bool all_owned = ((owned >> (lane & ~(CL_G - 1))) & ((1ull << CL_G) - 1)) == (1ull << CL_G) - 1;
+        if (k < ncl && m == 0) {
+            const int kk = c0 + k;
+            b.blo[kk] = make_double4(l[0], l[1], l[2], 0.0);
+            b.bhi[kk] = make_double4(h[0], h[1], h[2], 0.0);
+            b.fbox[2 * (size_t)kk] = make_float4(__double2float_rd(l[0]), __double2float_rd(l[1]), __double2float_rd(l[2]), all_owned ? 1.f : 0.f);
+            b.fbox[2 * (size_t)kk + 1] = make_float4(__double2float_ru(h[0]), __double2float_ru(h[1]), __double2float_ru(h[2]), 0.f);
+        }
     }
 }
 
