@@ -1,0 +1,105 @@
+"""Random plans and systems: one evaluation on the GPU against the CPU oracle (tests/oracle_lib.py), energies to 1e-12 of
+the largest component and accelerations to 1e-12 relative RMS.  A search for cases the fixed test cases miss; prints the
+cases that fail (none is the expected outcome).  Test infrastructure: the oracle is the checker.
+
+    python tests/fuzz_parity.py [cases] [seed]        (test_gpu_parity.py runs a fixed batch of it)
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+import oracle_lib as O
+
+
+def make_case(rng, case):
+    """Plan parameters, positions and charges of one random case (None where the helpers make no plan of the parameters)."""
+    import msm_amd
+    N = int(rng.choice([40, 200, 900, 3000, 9000, 30000]))
+    A = tuple(float(x) for x in rng.uniform(0.8, 1.7, 3)) if rng.random() < 0.6 else (1.0, 1.0, 1.0)
+    p = int(rng.choice([4, 6]))
+    mu = int(rng.choice([4, 6, 10]))
+    abar = float(rng.uniform(3.0, 5.0))
+    L = int(rng.choice([0, 1, 2, 3]))
+    kind = int(rng.integers(0, 4))
+    # (every random number of the case is drawn before anything can fail, so that a case does not depend on the ones before)
+    ball_centre, ball = rng.uniform(0.2, 0.8, 3), rng.standard_normal((N // 5, 3))
+    sheet = rng.random(N)
+    try:
+        desc = msm_amd.plan_auto(N, A, p, mu, abar, L)
+    except msm_amd.MsmAmdError:
+        return None      # (a grid that the requested number of levels does not divide)
+    r, q = O.neutral_system(N, A, seed=1000 + case)
+    if kind == 1:     # a crowded ball: long lists, overflowing ones, long runs in the grid transfer
+        r[:N // 5] = (np.array(A) * ball_centre + 0.02 * min(A) * ball) % np.array(A)
+    elif kind == 2:   # particles on faces and corners of the cell, and outside it
+        # (no two of them the same point after wrapping: coincident charges have no finite energy)
+        pts = [[0, 0, 0], [A[0], 0.3 * A[1], 0], [0.2 * A[0], A[1], A[2]], [A[0] * 1.5, -0.75 * A[1], 0.5 * A[2]],
+               [0.5 * A[0], 0.5 * A[1], 0], [A[0] * (1 - 1e-16), 0.6 * A[1], 0], [0.7 * A[0], 0, A[2] * 2],
+               [-1e-300, 0.1 * A[1], 0.9 * A[2]]]
+        r[:min(N, 8)] = pts[:min(N, 8)]
+    elif kind == 3:   # a sheet of particles: empty columns and tiles elsewhere
+        r[:, 2] = (0.45 + 0.1 * sheet) * A[2]
+    return desc, r, q, kind, (N, A, p, mu, abar, L)
+
+
+def run(ncases, seed, quiet=False):
+    import torch
+    import msm_amd
+    rng = np.random.default_rng(seed)
+    say = (lambda *a, **k: None) if quiet else print
+    failures = []
+    for case in range(ncases):
+        made = make_case(rng, case)
+        if made is None:
+            continue
+        desc, r, q, kind, (N, A, p, mu, abar, L) = made
+        t0 = time.time()
+        sp = O.SpecPlan.explicit(desc.N, list(desc.A), list(desc.M), desc.p, desc.mu, desc.L, desc.a, desc.beta, desc.kmax, nthreads=8)
+        ref = sp.eval(r, q)
+        eng = msm_amd.Engine(desc)
+        en, acc = eng.eval(torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0"))
+        acc = acc.cpu().numpy()
+        eng.close()
+        en_ref, acc_ref = np.asarray(ref["energies"]), np.asarray(ref["acc"])
+        scale = np.abs(en_ref[:6]).max()
+        de = np.abs(np.asarray(en)[:7] - en_ref[:7]).max() / scale
+        den = max(np.sqrt((acc_ref ** 2).sum()), 1e-300)
+        da = np.sqrt(((acc - acc_ref) ** 2).sum()) / den
+        # a crowded ball holds pairs 1e-5 apart and closer: the last bit of a wrapped coordinate (the two sides wrap in their
+        # own ways) is 1e-11 of such a distance, and of the force of that pair, which dominates the norm (1.1e-11 seen in
+        # 400 cases, all of it in the short-range part of the closest pair; the rest of the sum agreed to 1e-17)
+        tol_acc = 1e-10 if kind == 1 else 1e-12
+        ok = bool(de < 1e-12 and da < tol_acc and np.isfinite(acc).all())
+        line = ("case %3d %s N %6d A %s p %d mu %2d abar %.2f L %d -> M %s L %d kind %d: energy %.1e acc %.1e  (%.1f s)" %
+                (case, "ok  " if ok else "FAIL", N, tuple(round(x, 3) for x in A), p, mu, abar, L, list(desc.M), desc.L, kind, de, da,
+                 time.time() - t0))
+        say(line, flush=True)
+        if ok:
+            continue
+        failures.append(line)
+        if np.isfinite(acc).all():
+            # where the difference sits: the short-range part alone (stage by stage) and what is left
+            eng2 = msm_amd.Engine(desc)
+            eng2.stage_bin(torch.as_tensor(r, device="cuda:0"), torch.as_tensor(q, device="cuda:0"))
+            acc_s = torch.zeros((N, 3), dtype=torch.float64, device="cuda:0")
+            eng2.stage_pairs(acc_s)
+            acc_s = acc_s.cpu().numpy()
+            aw = sp.pairs(r, q)[0]
+            ds = np.sqrt(((acc_s - aw) ** 2).sum()) / den
+            dl = np.sqrt((((acc - acc_s) - (acc_ref - aw)) ** 2).sum()) / den
+            worst = np.argsort(-np.abs(acc - acc_ref).max(axis=1))[:3]
+            say("      short-range part %.1e, the rest %.1e (both over the norm of the whole); worst particles %s: diff %s of %s"
+                % (ds, dl, worst.tolist(), np.abs(acc - acc_ref).max(axis=1)[worst].tolist(), np.abs(acc_ref).max(axis=1)[worst].tolist()))
+            eng2.close()
+    return failures
+
+
+if __name__ == "__main__":
+    bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print("failures:", len(bad))
+    sys.exit(1 if bad else 0)

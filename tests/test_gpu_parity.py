@@ -1333,3 +1333,13 @@ def test_eval_reuse_small_and_skewed_plans(msm, torch, N, A, p, L):
     assert kept.reuse_stats() == (6, 2)
     fresh.close()
     kept.close()
+
+
+def test_random_plans_against_the_oracle(msm, torch):
+    """A fixed batch of tests/fuzz_parity.py: random particle counts, cells of unequal edges, both spline orders, cutoffs
+    of 3 to 5 grid spacings, one to three levels, on uniform systems, crowded balls, sheets, and particles on the faces of
+    the cell and outside it - one evaluation each against the oracle, 1e-12 (1e-10 for the accelerations of the crowded
+    balls, whose closest pairs are 1e-5 apart and closer: the last bit of a wrapped coordinate is 1e-11 of their force)."""
+    import fuzz_parity
+    failures = fuzz_parity.run(36, 7, quiet=True)
+    assert not failures, "\n".join(failures)
