@@ -19,11 +19,14 @@ import oracle_lib as O
 def make_case(rng, case):
     """Plan parameters, positions and charges of one random case (None where the helpers make no plan of the parameters)."""
     import msm_amd
-    N = int(rng.choice([40, 200, 900, 3000, 9000, 30000]))
+    # FUZZ_N="n1,n2,...", FUZZ_ABAR="lo,hi": other particle counts and cutoffs (in grid spacings) than the default ranges
+    sizes = [int(x) for x in os.environ.get("FUZZ_N", "40,200,900,3000,9000,30000").split(",")]
+    alo, ahi = [float(x) for x in os.environ.get("FUZZ_ABAR", "3.0,5.0").split(",")]
+    N = int(rng.choice(sizes))
     A = tuple(float(x) for x in rng.uniform(0.8, 1.7, 3)) if rng.random() < 0.6 else (1.0, 1.0, 1.0)
     p = int(rng.choice([4, 6]))
     mu = int(rng.choice([4, 6, 10]))
-    abar = float(rng.uniform(3.0, 5.0))
+    abar = float(rng.uniform(alo, ahi))
     L = int(rng.choice([0, 1, 2, 3]))
     kind = int(rng.integers(0, 4))
     # (every random number of the case is drawn before anything can fail, so that a case does not depend on the ones before)
